@@ -1,0 +1,306 @@
+// rr_api.hip -- host side of librodent_hip.so: model blob loader, device upload of the kernel
+// tables, LDS / debug layouts and the launch wrappers behind the C ABI of include/rodent_rr.h.
+#include "../../include/rodent_rr.h"
+#include "rr_kernel.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+extern "C" const char* rr_last_error(void) { return g_err.c_str(); }
+
+#define HIPCHK(x)                                                                                  \
+  do {                                                                                             \
+    hipError_t e_ = (x);                                                                           \
+    if (e_ != hipSuccess) return fail(RR_EHIP, std::string(#x) + ": " + hipGetErrorString(e_));   \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------ model
+struct Entry { int dtype, ndim, dims[4]; size_t count; const void* data; };
+
+struct rr_model {
+  std::vector<unsigned char> raw;
+  std::map<std::string, Entry> e;
+  rr_dims dims;
+  RRDims kd;
+  std::vector<std::string> dbg_names;
+  std::vector<int32_t> dbg_off, dbg_size;
+  std::vector<const char*> dbg_cnames;
+  int NBS, NVS, NCS;
+
+  const Entry* find(const char* n) const { auto it = e.find(n); return it == e.end() ? nullptr : &it->second; }
+  int iscalar(const char* n) const { const Entry* x = find(n); return x ? ((const int32_t*)x->data)[0] : 0; }
+  float fscalar(const char* n, int i = 0) const { const Entry* x = find(n); return x ? ((const float*)x->data)[i] : 0.f; }
+};
+
+static void layout(rr_model* m) {
+  RRDims& k = m->kd;
+  const rr_dims& d = m->dims;
+  int o = 0;
+  auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
+  k.o_qpos = take(d.nq); k.o_qvel = take(d.nv); k.o_act = take(d.nu); k.o_ctrl = take(d.nu);
+  k.o_xpos = take(3 * d.nbody); k.o_xquat = take(4 * d.nbody); k.o_xmat = take(9 * d.nbody);
+  k.o_cinert = take(10 * d.nbody); k.o_crb = take(10 * d.nbody); k.o_cdof = take(6 * d.nv);
+  k.o_cvel = take(6 * d.nbody); k.o_cacc = take(6 * d.nbody); k.o_cfrc = take(6 * d.nbody); k.o_buf = take(6 * d.nv);
+  k.o_qM = take(d.nM); k.o_qLD = take(d.nM);
+  const int32_t* jadr = (const int32_t*)m->find("con_jadr")->data;
+  k.nJ = jadr[d.ncon];
+  k.o_J = take(jadr[d.ncon]); k.o_cf = take(3 * d.ncon); k.o_vec = take(d.nv); k.o_x = take(d.nv);
+  k.lds_floats = o;
+  // debug dump
+  int g = 0;
+  auto dbg = [&](const char* name, int n) { int r = g; m->dbg_names.push_back(name); m->dbg_off.push_back(g); m->dbg_size.push_back(n); g += n; return r; };
+  k.g_xpos = dbg("xpos", 3 * d.nbody); k.g_xquat = dbg("xquat", 4 * d.nbody); k.g_xmat = dbg("xmat", 9 * d.nbody);
+  k.g_com = dbg("subtree_com", 6); k.g_cinert = dbg("cinert", 10 * d.nbody); k.g_crb = dbg("crb", 10 * d.nbody);
+  k.g_cdof = dbg("cdof", 6 * d.nv); k.g_cvel = dbg("cvel", 6 * d.nbody); k.g_cfrc = dbg("cfrc", 6 * d.nbody);
+  k.g_qM = dbg("qM", d.nM); k.g_qLD = dbg("qLD", d.nM); k.g_dinv = dbg("qLDiagInv", d.nv);
+  k.g_bias = dbg("qfrc_bias", d.nv); k.g_passive = dbg("qfrc_passive", d.nv); k.g_actuator = dbg("qfrc_actuator", d.nv);
+  k.g_smooth = dbg("qfrc_smooth", d.nv); k.g_qacc_smooth = dbg("qacc_smooth", d.nv);
+  k.g_con_dist = dbg("con_dist", d.ncon); k.g_con_pos = dbg("con_pos", 3 * d.ncon); k.g_con_frame = dbg("con_frame", 9 * d.ncon);
+  k.g_con_D = dbg("con_D", d.ncon); k.g_con_aref = dbg("con_aref", 4 * d.ncon); k.g_lim = dbg("limit_pos_D_aref", 3 * d.nv);
+  k.g_qacc = dbg("qacc", d.nv); k.g_qfrc_constraint = dbg("qfrc_constraint", d.nv); k.g_misc = dbg("niter_cost", 2);
+  k.g_J = dbg("J", jadr[d.ncon]);
+  k.dbg_floats = g;
+  for (auto& s : m->dbg_names) m->dbg_cnames.push_back(s.c_str());
+  m->dims.lds_bytes = o * (int)sizeof(float);
+  m->dims.dbg_floats = g;
+}
+
+extern "C" int rr_model_load(const char* path, rr_model** out) {
+  if (!path || !out) return fail(RR_EINVAL, "rr_model_load: null argument");
+  FILE* f = fopen(path, "rb");
+  if (!f) return fail(RR_EIO, std::string("rr_model_load: cannot open ") + path);
+  fseek(f, 0, SEEK_END);
+  long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  rr_model* m = new rr_model();
+  m->raw.resize(n);
+  size_t got = fread(m->raw.data(), 1, n, f);
+  fclose(f);
+  if ((long)got != n || n < 8 || memcmp(m->raw.data(), "RRM1", 4)) { delete m; return fail(RR_EIO, "rr_model_load: not an RRM1 blob"); }
+  const unsigned char* raw = m->raw.data();
+  uint32_t ne = *(const uint32_t*)(raw + 4);
+  if (8 + (size_t)ne * 72 > (size_t)n) { delete m; return fail(RR_EIO, "rr_model_load: truncated header"); }
+  const unsigned char* p = raw + 8;
+  for (uint32_t i = 0; i < ne; ++i, p += 72) {
+    Entry e;
+    char name[33] = {0};
+    memcpy(name, p, 32);
+    e.dtype = *(const uint32_t*)(p + 32);
+    e.ndim = *(const uint32_t*)(p + 36);
+    for (int k = 0; k < 4; ++k) e.dims[k] = *(const uint32_t*)(p + 40 + 4 * k);
+    uint64_t off = *(const uint64_t*)(p + 56), nb = *(const uint64_t*)(p + 64);
+    if (off + nb > (uint64_t)n) { delete m; return fail(RR_EIO, "rr_model_load: entry out of range"); }
+    e.count = nb / 4;
+    e.data = raw + off;
+    m->e[name] = e;
+  }
+  static const char* need[] = {"nq", "nv", "nu", "nbody", "njnt", "ngeom", "nM", "ncon", "nlimit", "nefc", "obs_dim", "k_slots",
+                               "k_lvl_adr", "k_lvl_body", "k_child", "k_body_i", "k_body_f", "k_jnt_i", "k_jnt_f", "k_dof_i",
+                               "k_dof_f", "k_act_f", "k_M_ij", "k_M_rowadr", "k_tri", "k_mulm", "k_solve_fwd", "k_solve_bwd",
+                               "k_solve_bwd_adr", "k_con_i", "k_con_f", "k_con_chain", "k_jtf", "k_root_mass", "con_jadr",
+                               "dof_depth", "body_depth", "opt_timestep", "opt_gravity", "stat_meaninertia"};
+  for (const char* nme : need)
+    if (!m->find(nme)) { std::string s = std::string("rr_model_load: blob lacks '") + nme + "'"; delete m; return fail(RR_EIO, s); }
+  rr_dims& d = m->dims;
+  memset(&d, 0, sizeof(d));
+  d.nq = m->iscalar("nq"); d.nv = m->iscalar("nv"); d.nu = m->iscalar("nu"); d.na = m->iscalar("na"); d.nbody = m->iscalar("nbody");
+  d.njnt = m->iscalar("njnt"); d.ngeom = m->iscalar("ngeom"); d.nM = m->iscalar("nM"); d.ncon = m->iscalar("ncon");
+  d.nlimit = m->iscalar("nlimit"); d.nefc = m->iscalar("nefc"); d.obs_dim = m->iscalar("obs_dim");
+  d.iterations = m->iscalar("opt_iterations"); d.ls_iterations = m->iscalar("opt_ls_iterations");
+  d.timestep = m->fscalar("opt_timestep");
+  const int32_t* sl = (const int32_t*)m->find("k_slots")->data;
+  m->NBS = sl[0]; m->NVS = sl[1]; m->NCS = sl[2];
+  RRDims& k = m->kd;
+  memset(&k, 0, sizeof(k));
+  k.nq = d.nq; k.nv = d.nv; k.nu = d.nu; k.nbody = d.nbody; k.njnt = d.njnt; k.nM = d.nM; k.ncon = d.ncon;
+  const Entry* la = m->find("k_lvl_adr");
+  k.nlevel = (int)la->count - 2;
+  int dmax = 0;
+  { const Entry* dd = m->find("dof_depth"); for (size_t i = 0; i < dd->count; ++i) dmax = std::max(dmax, ((const int32_t*)dd->data)[i]); }
+  k.dmax = dmax;
+  k.nroot = (int)m->find("k_root_mass")->count;
+  k.T_mulm = m->find("k_mulm")->dims[0]; k.T_jtf = m->find("k_jtf")->dims[0]; k.T_chain = m->find("k_con_chain")->dims[0];
+  k.obs_dim = d.obs_dim; k.iterations = d.iterations; k.ls_iterations = d.ls_iterations;
+  k.dt = d.timestep; k.gx = m->fscalar("opt_gravity", 0); k.gy = m->fscalar("opt_gravity", 1); k.gz = m->fscalar("opt_gravity", 2);
+  k.tolerance = m->fscalar("opt_tolerance"); k.ls_tolerance = m->fscalar("opt_ls_tolerance");
+  k.meaninertia = m->fscalar("stat_meaninertia");
+  if (k.nroot > 2) { delete m; return fail(RR_EUNSUPPORTED, "rr_model_load: more than 2 kinematic trees"); }
+  if (d.nv > 256 || d.ncon > 256) { delete m; return fail(RR_EUNSUPPORTED, "rr_model_load: nv/ncon above the 8-bit table index"); }
+  if (m->find("k_mulm")->dims[1] != m->NVS * RR_LANES || m->find("k_con_chain")->dims[1] != m->NCS * RR_LANES) {
+    delete m; return fail(RR_EIO, "rr_model_load: lane-table width mismatch");
+  }
+  layout(m);
+  *out = m;
+  return RR_OK;
+}
+
+extern "C" int rr_model_dims(const rr_model* m, rr_dims* out) {
+  if (!m || !out) return fail(RR_EINVAL, "rr_model_dims: null argument");
+  *out = m->dims;
+  return RR_OK;
+}
+extern "C" int rr_model_set_solver(rr_model* m, int32_t it, int32_t ls) {
+  if (!m || it < 0 || ls < 0) return fail(RR_EINVAL, "rr_model_set_solver: bad argument");
+  m->dims.iterations = m->kd.iterations = it;
+  m->dims.ls_iterations = m->kd.ls_iterations = ls;
+  return RR_OK;
+}
+extern "C" void rr_model_destroy(rr_model* m) { delete m; }
+
+// ------------------------------------------------------------------------------------------ batch
+struct rr_batch {
+  const rr_model* m;
+  int N, device;
+  hipStream_t stream;
+  RRDims kd;
+  RRTables T;
+  std::vector<void*> dev_allocs;
+  bool timing = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double total_ms = 0;
+  int64_t launches = 0;
+  bool pending = false;
+};
+
+template <typename Tp>
+static int upload(rr_batch* b, const char* name, const Tp** dst) {
+  const Entry* e = b->m->find(name);
+  void* p = nullptr;
+  size_t bytes = std::max<size_t>(e->count, 1) * 4;
+  HIPCHK(hipMalloc(&p, bytes));
+  b->dev_allocs.push_back(p);
+  if (e->count) HIPCHK(hipMemcpy(p, e->data, e->count * 4, hipMemcpyHostToDevice));
+  *dst = (const Tp*)p;
+  return RR_OK;
+}
+
+typedef void (*kern_t)(const RRDims, const RRTables, const RRIO, const int, const int);
+static kern_t pick_kernel(int nbs, int nvs, int ncs) {
+  if (nbs == 1 && nvs == 1 && ncs == 1) return rr_step_kernel<1, 1, 1>;
+  if (nbs == 2 && nvs == 2 && ncs == 1) return rr_step_kernel<2, 2, 1>;
+  if (nbs == 3 && nvs == 3 && ncs == 2) return rr_step_kernel<3, 3, 2>;
+  return nullptr;
+}
+
+extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t device, void* stream, rr_batch** out) {
+  if (!m || !out || num_envs <= 0) return fail(RR_EINVAL, "rr_batch_create: bad argument");
+  if (!pick_kernel(m->NBS, m->NVS, m->NCS)) return fail(RR_EUNSUPPORTED, "rr_batch_create: no kernel instance for this model's slot counts");
+  HIPCHK(hipSetDevice(device));
+  rr_batch* b = new rr_batch();
+  b->m = m; b->N = num_envs; b->device = device; b->stream = (hipStream_t)stream; b->kd = m->kd;
+  int rc = 0;
+#define UP(field, name) if ((rc = upload(b, name, &b->T.field))) { rr_batch_destroy(b); return rc; }
+  UP(lvl_adr, "k_lvl_adr") UP(lvl_body, "k_lvl_body") UP(child, "k_child") UP(body_i, "k_body_i") UP(jnt_i, "k_jnt_i")
+  UP(dof_i, "k_dof_i") UP(M_ij, "k_M_ij") UP(M_rowadr, "k_M_rowadr") UP(tri, "k_tri") UP(mulm, "k_mulm")
+  UP(solve_fwd, "k_solve_fwd") UP(solve_bwd, "k_solve_bwd") UP(solve_bwd_adr, "k_solve_bwd_adr") UP(con_i, "k_con_i")
+  UP(con_chain, "k_con_chain") UP(jtf, "k_jtf") UP(body_f, "k_body_f") UP(jnt_f, "k_jnt_f") UP(dof_f, "k_dof_f")
+  UP(act_f, "k_act_f") UP(con_f, "k_con_f") UP(root_mass, "k_root_mass")
+#undef UP
+  kern_t kern = pick_kernel(m->NBS, m->NVS, m->NCS);
+  if (m->dims.lds_bytes > 160 * 1024) { rr_batch_destroy(b); return fail(RR_EUNSUPPORTED, "rr_batch_create: per-env working set exceeds 160 KiB LDS"); }
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, m->dims.lds_bytes);
+  if (e != hipSuccess) { rr_batch_destroy(b); return fail(RR_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
+  *out = b;
+  return RR_OK;
+}
+
+extern "C" void rr_batch_destroy(rr_batch* b) {
+  if (!b) return;
+  for (void* p : b->dev_allocs) (void)hipFree(p);
+  if (b->ev0) (void)hipEventDestroy(b->ev0);
+  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  delete b;
+}
+
+static int collect_timing(rr_batch* b) {
+  if (b->pending) {
+    HIPCHK(hipEventSynchronize(b->ev1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+    b->total_ms += ms;
+    b->launches += 1;
+    b->pending = false;
+  }
+  return RR_OK;
+}
+
+static int launch(rr_batch* b, const rr_state* st, const float* ctrl, int n_frames, const rr_env_io* env, const rr_outputs* out, int mode) {
+  if (!b || !st || !st->qpos || !st->qvel || !st->act || !st->qacc_warmstart) return fail(RR_EINVAL, "launch: null state pointer");
+  if ((mode & 1) && (!ctrl || n_frames <= 0)) return fail(RR_EINVAL, "launch: step needs ctrl and n_frames > 0");
+  RRIO io;
+  memset(&io, 0, sizeof(io));
+  io.qpos = st->qpos; io.qvel = st->qvel; io.act = st->act; io.warm = st->qacc_warmstart; io.ctrl = ctrl;
+  if (out) {
+    io.o_cinert = out->cinert; io.o_cvel = out->cvel; io.o_qfrc_actuator = out->qfrc_actuator; io.o_xpos = out->xpos;
+    io.o_xmat = out->xmat; io.o_com = out->subtree_com; io.dbg = out->debug;
+  }
+  if (env) {
+    if (!env->obs || !env->track_pos || !env->cur_frame || env->track_len <= 0) return fail(RR_EINVAL, "launch: env io needs obs, track_pos, cur_frame");
+    if ((mode & 1) && (!env->reward || !env->done || !env->metrics)) return fail(RR_EINVAL, "launch: env step needs reward, done, metrics");
+    io.track_pos = env->track_pos; io.track_len = env->track_len; io.cur_frame = env->cur_frame; io.obs = env->obs;
+    io.reward = env->reward; io.done = env->done; io.metrics = env->metrics;
+    io.healthy_reward = env->healthy_reward; io.ctrl_cost_weight = env->ctrl_cost_weight; io.z_min = env->healthy_z_min;
+    io.z_max = env->healthy_z_max; io.terminate_when_unhealthy = env->terminate_when_unhealthy;
+  }
+  io.mode = mode;
+  HIPCHK(hipSetDevice(b->device));
+  kern_t kern = pick_kernel(b->m->NBS, b->m->NVS, b->m->NCS);
+  RRDims kd = b->kd;
+  kd.iterations = b->m->kd.iterations; kd.ls_iterations = b->m->kd.ls_iterations;
+  if (b->timing) {
+    int rc = collect_timing(b);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(b->ev0, b->stream));
+  }
+  hipLaunchKernelGGL(kern, dim3(b->N), dim3(RR_LANES), (size_t)b->m->dims.lds_bytes, b->stream, kd, b->T, io, b->N, n_frames);
+  HIPCHK(hipGetLastError());
+  if (b->timing) {
+    HIPCHK(hipEventRecord(b->ev1, b->stream));
+    b->pending = true;
+  }
+  return RR_OK;
+}
+
+extern "C" int rr_pipeline_init(rr_batch* b, const rr_state* st, const rr_outputs* out) { return launch(b, st, nullptr, 1, nullptr, out, 0); }
+extern "C" int rr_pipeline_step(rr_batch* b, const rr_state* st, const float* ctrl, int32_t n_frames, const rr_outputs* out) {
+  return launch(b, st, ctrl, n_frames, nullptr, out, 1);
+}
+extern "C" int rr_env_step(rr_batch* b, const rr_state* st, const float* action, int32_t n_frames, const rr_env_io* env, const rr_outputs* out) {
+  if (!env) return fail(RR_EINVAL, "rr_env_step: env io required");
+  return launch(b, st, action, n_frames, env, out, 1);
+}
+extern "C" int rr_env_reset(rr_batch* b, const rr_state* st, const rr_env_io* env, const rr_outputs* out) {
+  if (!env) return fail(RR_EINVAL, "rr_env_reset: env io required");
+  return launch(b, st, nullptr, 1, env, out, 2);
+}
+
+extern "C" int rr_debug_layout(const rr_batch* b, const char*** names, const int32_t** offsets, const int32_t** sizes) {
+  if (!b) return fail(RR_EINVAL, "rr_debug_layout: null batch");
+  if (names) *names = const_cast<const char**>(b->m->dbg_cnames.data());
+  if (offsets) *offsets = b->m->dbg_off.data();
+  if (sizes) *sizes = b->m->dbg_size.data();
+  return (int)b->m->dbg_names.size();
+}
+
+extern "C" int rr_batch_set_timing(rr_batch* b, int32_t enable) {
+  if (!b) return fail(RR_EINVAL, "rr_batch_set_timing: null batch");
+  HIPCHK(hipSetDevice(b->device));
+  if (enable && !b->ev0) { HIPCHK(hipEventCreate(&b->ev0)); HIPCHK(hipEventCreate(&b->ev1)); }
+  b->timing = enable != 0;
+  b->total_ms = 0; b->launches = 0; b->pending = false;
+  return RR_OK;
+}
+extern "C" int rr_batch_kernel_time(rr_batch* b, double* total_ms, int64_t* launches) {
+  if (!b) return fail(RR_EINVAL, "rr_batch_kernel_time: null batch");
+  int rc = collect_timing(b);
+  if (rc) return rc;
+  if (total_ms) *total_ms = b->total_ms;
+  if (launches) *launches = b->launches;
+  return RR_OK;
+}

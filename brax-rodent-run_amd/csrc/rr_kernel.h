@@ -1,0 +1,1095 @@
+// rr_kernel.h -- fused per-environment physics step for gfx950 (MI355X): ONE 64-lane wavefront per
+// environment, the whole working set of an environment resident in LDS for all n_frames substeps.
+//
+// Path replaced: brax.mjx.pipeline.step -> mujoco.mjx.step (kinematics, com_pos, crb, factor_m,
+// collision, make_constraint, com_vel, passive, rne, fwd_actuation, fwd_acceleration, CG solve, euler)
+// [REF Rodent_Env_Brax.py:101 -> UP mjx; SURVEY.md Appendix A], plus the env epilogue
+// [REF Rodent_Env_Brax.py:103-158].
+//
+// Mapping: lanes run over bodies / dofs / contacts (element e -> lane e%64, slot e/64,
+// slot counts are template parameters so per-lane arrays stay in registers).  Kinematic-tree
+// recursions are level-synchronous sweeps; the sparse L'DL factor/solve, M*x and J'f products are
+// driven by the lane-major index tables built in rodent_amd/ktables.py.  Reductions over dofs / rows
+// are wavefront butterflies.  Inactive constraint rows contribute exactly zero in the reference
+// formulation, so they are skipped.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RR_LANES 64
+#define RR_MINVAL 1e-15f
+#define RR_MINIMP 0.0001f
+#define RR_MAXIMP 0.9999f
+
+struct RRDims {
+  int nq, nv, nu, nbody, njnt, nM, ncon, nlevel, dmax, nroot;
+  int T_mulm, T_jtf, T_chain, obs_dim, iterations, ls_iterations, nJ;
+  float dt, gx, gy, gz, tolerance, ls_tolerance, meaninertia;
+  // LDS offsets (floats)
+  int o_qpos, o_qvel, o_act, o_ctrl, o_xpos, o_xquat, o_xmat, o_cinert, o_crb, o_cdof, o_cvel, o_cacc, o_cfrc, o_buf,
+      o_qM, o_qLD, o_J, o_cf, o_vec, o_x, lds_floats;
+  // debug dump offsets (floats)
+  int g_xpos, g_xquat, g_xmat, g_com, g_cinert, g_crb, g_cdof, g_cvel, g_cfrc, g_qM, g_qLD, g_dinv, g_bias, g_passive,
+      g_actuator, g_smooth, g_qacc_smooth, g_con_dist, g_con_pos, g_con_frame, g_con_D, g_con_aref, g_lim, g_qacc,
+      g_qfrc_constraint, g_misc, g_J, dbg_floats;
+};
+
+struct RRTables {
+  const int *lvl_adr, *lvl_body, *child, *body_i, *jnt_i, *dof_i, *M_ij, *M_rowadr, *tri, *mulm, *solve_fwd, *solve_bwd,
+      *solve_bwd_adr, *con_i, *con_chain, *jtf;
+  const float *body_f, *jnt_f, *dof_f, *act_f, *con_f, *root_mass;
+};
+
+struct RRIO {
+  float *qpos, *qvel, *act, *warm;
+  const float* ctrl;
+  float *o_cinert, *o_cvel, *o_qfrc_actuator, *o_xpos, *o_xmat, *o_com, *dbg;
+  // env epilogue
+  const float* track_pos;
+  int track_len;
+  int* cur_frame;
+  float *obs, *reward, *done, *metrics;
+  float healthy_reward, ctrl_cost_weight, z_min, z_max;
+  int terminate_when_unhealthy;
+  int mode;  // 0 = forward only (pipeline_init), 1 = step; bit 1 (2) = env epilogue as reset (obs only)
+};
+
+// ------------------------------------------------------------------------------------------ small math
+struct v3 { float x, y, z; };
+__device__ __forceinline__ v3 mk3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ v3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+__device__ __forceinline__ void st3(float* p, v3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+__device__ __forceinline__ v3 operator+(v3 a, v3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ v3 operator-(v3 a, v3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ v3 operator*(v3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ v3 cross(v3 a, v3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+
+__device__ __forceinline__ void quat_mul(float* r, const float* a, const float* b) {
+  float w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  float x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  float y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  float z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+__device__ __forceinline__ void quat_to_mat(float* m, const float* q) {
+  float w = q[0], x = q[1], y = q[2], z = q[3];
+  m[0] = w * w + x * x - y * y - z * z; m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
+}
+__device__ __forceinline__ v3 mat_vec(const float* m, v3 v) {
+  return mk3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z);
+}
+__device__ __forceinline__ void quat_normalize(float* q) {
+  float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < RR_MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+  q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+// spatial inertia (xx yy zz xy xz yz, m*off(3), m) times motion vector (ang; lin)
+__device__ __forceinline__ void mul_inert_vec(float* res, const float* i, const float* v) {
+  res[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  res[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  res[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  res[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  res[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  res[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+__device__ __forceinline__ void cross_motion(float* res, const float* vel, const float* v) {
+  res[0] = -vel[2] * v[1] + vel[1] * v[2];
+  res[1] = vel[2] * v[0] - vel[0] * v[2];
+  res[2] = -vel[1] * v[0] + vel[0] * v[1];
+  res[3] = -vel[2] * v[4] + vel[1] * v[5] - vel[5] * v[1] + vel[4] * v[2];
+  res[4] = vel[2] * v[3] - vel[0] * v[5] + vel[5] * v[0] - vel[3] * v[2];
+  res[5] = -vel[1] * v[3] + vel[0] * v[4] - vel[4] * v[0] + vel[3] * v[1];
+}
+__device__ __forceinline__ void cross_force(float* res, const float* vel, const float* f) {
+  res[0] = -vel[2] * f[1] + vel[1] * f[2] - vel[5] * f[4] + vel[4] * f[5];
+  res[1] = vel[2] * f[0] - vel[0] * f[2] + vel[5] * f[3] - vel[3] * f[5];
+  res[2] = -vel[1] * f[0] + vel[0] * f[1] - vel[4] * f[3] + vel[3] * f[4];
+  res[3] = -vel[2] * f[4] + vel[1] * f[5];
+  res[4] = vel[2] * f[3] - vel[0] * f[5];
+  res[5] = -vel[1] * f[3] + vel[0] * f[4];
+}
+__device__ __forceinline__ float dot6(const float* a, const float* b) {
+  float s = a[0] * b[0];
+  s += a[1] * b[1]; s += a[2] * b[2]; s += a[3] * b[3]; s += a[4] * b[4]; s += a[5] * b[5];
+  return s;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+template <int K>
+__device__ __forceinline__ void wave_sum_n(float* v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += __shfl_xor(v[k], o);
+  }
+}
+
+// solver impedance [UP mjx constraint._kbi]
+__device__ __forceinline__ void kbi(float dt, float sr0, float sr1, const float* si, float pos, float& k, float& b, float& imp) {
+  float timeconst = fmaxf(sr0, 2.0f * dt);
+  float dmin = fminf(fmaxf(si[0], RR_MINIMP), RR_MAXIMP), dmax = fminf(fmaxf(si[1], RR_MINIMP), RR_MAXIMP);
+  float width = fmaxf(RR_MINVAL, si[2]);
+  float mid = fminf(fmaxf(si[3], RR_MINIMP), RR_MAXIMP);
+  float power = fmaxf(1.0f, si[4]);
+  k = 1.0f / (dmax * dmax * timeconst * timeconst * sr1 * sr1);
+  b = 2.0f / (dmax * timeconst);
+  if (sr0 <= 0) k = -sr0 / (dmax * dmax);
+  if (sr1 <= 0) b = -sr1 / dmax;
+  float x = fabsf(pos) / width;
+  float a_ = (1.0f / powf(mid, power - 1.0f)) * powf(x, power);
+  float bb = 1.0f - (1.0f / powf(1.0f - mid, power - 1.0f)) * powf(1.0f - x, power);
+  float y = x < mid ? a_ : bb;
+  imp = dmin + y * (dmax - dmin);
+  imp = fminf(fmaxf(imp, dmin), dmax);
+  if (x > 1.0f) imp = dmax;
+}
+
+struct LSPoint { float alpha, cost, d0, d1; };
+
+// ------------------------------------------------------------------------------------------ the wave
+template <int NBS, int NVS, int NCS>
+struct Wave {
+  const RRDims& D;
+  const RRTables& T;
+  const int lane;
+  float* const lds;
+  float *s_qpos, *s_qvel, *s_act, *s_ctrl, *s_xpos, *s_xquat, *s_xmat, *s_cinert, *s_crb, *s_cdof, *s_cvel, *s_cacc,
+      *s_cfrc, *s_buf, *s_qM, *s_qLD, *s_J, *s_cf, *s_vec, *s_x;
+  static constexpr int W = NVS * RR_LANES;
+  static constexpr int WC = NCS * RR_LANES;
+
+  // per-dof registers (slot s -> dof lane + 64 s)
+  int dofdepth[NVS];
+  float dinv[NVS];
+  float qfrc_smooth[NVS], qfrc_actuator[NVS], qacc_smooth[NVS], act_dot[NVS];
+  float qacc[NVS], Ma[NVS], grad[NVS], Mgrad[NVS], search[NVS], mv[NVS], qfrc_con[NVS], warm[NVS];
+  // limit rows (one per limited hinge dof)
+  float lim_sign[NVS], lim_D[NVS], lim_aref[NVS], lim_jar[NVS], lim_jv[NVS];
+  bool lim_act[NVS];
+  // contact rows (4 pyramid rows per contact slot)
+  bool con_act[NCS];
+  float con_mu[NCS], con_D[NCS], con_aref[NCS][4], con_jar[NCS][4], con_jv[NCS][4];
+  int con_jadr[NCS], con_nanc[NCS];
+  unsigned long long amask[NCS];
+  float com0[3], com1[3];
+  float gauss, cost, prev_cost;
+
+  __device__ Wave(const RRDims& d, const RRTables& t, float* l)
+      : D(d), T(t), lane(threadIdx.x), lds(l) {
+    s_qpos = l + d.o_qpos; s_qvel = l + d.o_qvel; s_act = l + d.o_act; s_ctrl = l + d.o_ctrl;
+    s_xpos = l + d.o_xpos; s_xquat = l + d.o_xquat; s_xmat = l + d.o_xmat; s_cinert = l + d.o_cinert;
+    s_crb = l + d.o_crb; s_cdof = l + d.o_cdof; s_cvel = l + d.o_cvel; s_cacc = l + d.o_cacc; s_cfrc = l + d.o_cfrc;
+    s_buf = l + d.o_buf; s_qM = l + d.o_qM; s_qLD = l + d.o_qLD; s_J = l + d.o_J; s_cf = l + d.o_cf;
+    s_vec = l + d.o_vec; s_x = l + d.o_x;
+  }
+
+  // One wavefront owns the environment: its LDS instructions execute in program order, so a
+  // cross-lane hand-off through LDS needs no s_barrier and no vmcnt/lgkmcnt drain -- only that the
+  // compiler keeps the program order of the LDS accesses around this point.
+  __device__ __forceinline__ void sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+  __device__ __forceinline__ v3 get_com(int r) const {
+    return mk3(r ? com1[0] : com0[0], r ? com1[1] : com0[1], r ? com1[2] : com0[2]);
+  }
+  __device__ __forceinline__ bool con_bit(int c) const {
+    unsigned long long mk = amask[0];
+#pragma unroll
+    for (int i = 1; i < NCS; ++i) mk = (c >> 6) == i ? amask[i] : mk;
+    return (mk >> (c & 63)) & 1ull;
+  }
+  // wave-uniform predicate -> scalar branch
+  static __device__ __forceinline__ bool uni(bool p) { return __builtin_amdgcn_readfirstlane((int)p) != 0; }
+
+  // ---------------------------------------------------------------- A-1 kinematics (level sweep)
+  __device__ __forceinline__ void kinematics() {
+    for (int L = 1; L <= D.nlevel; ++L) {
+      const int a0 = T.lvl_adr[L], cnt = T.lvl_adr[L + 1] - a0;
+      if (lane < cnt) {
+        const int b = T.lvl_body[a0 + lane];
+        const int* bi = T.body_i + 8 * b;
+        const float* bf = T.body_f + 18 * b;
+        const int p = bi[0];
+        float quat[4], mat[9], pq[4], bq[4];
+        v3 pos = ld3(s_xpos + 3 * p) + mat_vec(s_xmat + 9 * p, ld3(bf));
+        for (int k = 0; k < 4; ++k) { pq[k] = s_xquat[4 * p + k]; bq[k] = bf[3 + k]; }
+        quat_mul(quat, pq, bq);
+        const int ja = bi[1], jn = bi[2];
+        int free_da = -1;
+        for (int jj = 0; jj < jn; ++jj) {
+          const int j = ja + jj;
+          const int* ji = T.jnt_i + 4 * j;
+          const float* jf = T.jnt_f + 8 * j;
+          const int qa = ji[1], da = ji[2];
+          if (ji[0] == 0) {  // free
+            pos = ld3(s_qpos + qa);
+            for (int k = 0; k < 4; ++k) quat[k] = s_qpos[qa + 3 + k];
+            quat_normalize(quat);
+            free_da = da;
+          } else {  // hinge
+            quat_to_mat(mat, quat);
+            v3 anchor = mat_vec(mat, ld3(jf)) + pos;
+            v3 axis = mat_vec(mat, ld3(jf + 3));
+            st3(s_cdof + 6 * da, axis);        // raw: axis ; anchor (finalised in com_pos)
+            st3(s_cdof + 6 * da + 3, anchor);
+            const float ang = s_qpos[qa] - jf[6];
+            const float sn = sinf(ang * 0.5f), cs = cosf(ang * 0.5f);
+            float ql[4] = {cs, jf[3] * sn, jf[4] * sn, jf[5] * sn}, qn[4];
+            quat_mul(qn, quat, ql);
+            for (int k = 0; k < 4; ++k) quat[k] = qn[k];
+            quat_to_mat(mat, quat);
+            pos = anchor - mat_vec(mat, ld3(jf));
+          }
+        }
+        quat_normalize(quat);
+        quat_to_mat(mat, quat);
+        st3(s_xpos + 3 * b, pos);
+        for (int k = 0; k < 4; ++k) s_xquat[4 * b + k] = quat[k];
+        for (int k = 0; k < 9; ++k) s_xmat[9 * b + k] = mat[k];
+        if (free_da >= 0) {
+          for (int k = 0; k < 3; ++k) {
+            st3(s_cdof + 6 * (free_da + 3 + k), mk3(mat[k], mat[3 + k], mat[6 + k]));
+            st3(s_cdof + 6 * (free_da + 3 + k) + 3, pos);
+          }
+        }
+      }
+      sync();
+    }
+  }
+
+  // ---------------------------------------------------------------- A-2 com_pos: subtree COM per root, cinert, cdof
+  __device__ __forceinline__ void com_pos() {
+    float acc[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    float xip[NBS][3];
+#pragma unroll
+    for (int s = 0; s < NBS; ++s) {
+      const int b = lane + RR_LANES * s;
+      xip[s][0] = xip[s][1] = xip[s][2] = 0;
+      if (b >= 1 && b < D.nbody) {
+        const float* bf = T.body_f + 18 * b;
+        v3 xi = ld3(s_xpos + 3 * b) + mat_vec(s_xmat + 9 * b, ld3(bf + 7));
+        xip[s][0] = xi.x; xip[s][1] = xi.y; xip[s][2] = xi.z;
+        const float mass = bf[14];
+        const int r = T.body_i[8 * b + 5];
+        if (r == 0) { acc[0][0] += mass * xi.x; acc[0][1] += mass * xi.y; acc[0][2] += mass * xi.z; }
+        else        { acc[1][0] += mass * xi.x; acc[1][1] += mass * xi.y; acc[1][2] += mass * xi.z; }
+      }
+    }
+    wave_sum_n<6>(&acc[0][0]);
+    {
+      const float rm0 = T.root_mass[0], rm1 = D.nroot > 1 ? T.root_mass[1] : 1.0f;
+      for (int k = 0; k < 3; ++k) { com0[k] = acc[0][k] / rm0; com1[k] = acc[1][k] / rm1; }
+    }
+#pragma unroll
+    for (int s = 0; s < NBS; ++s) {
+      const int b = lane + RR_LANES * s;
+      if (b >= 1 && b < D.nbody) {
+        const float* bf = T.body_f + 18 * b;
+        const int r = T.body_i[8 * b + 5];
+        float q[4], bq[4], iq[4], R[9];
+        for (int k = 0; k < 4; ++k) { bq[k] = s_xquat[4 * b + k]; iq[k] = bf[10 + k]; }
+        quat_mul(q, bq, iq);
+        quat_to_mat(R, q);
+        const float mass = bf[14];
+        const float I0 = bf[15], I1 = bf[16], I2 = bf[17];
+        const v3 cm = get_com(r);
+        const float d0 = xip[s][0] - cm.x, d1 = xip[s][1] - cm.y, d2 = xip[s][2] - cm.z;
+        float t[9];
+        for (int rr = 0; rr < 3; ++rr) { t[3 * rr] = R[3 * rr] * I0; t[3 * rr + 1] = R[3 * rr + 1] * I1; t[3 * rr + 2] = R[3 * rr + 2] * I2; }
+        float* c = s_cinert + 10 * b;
+        c[0] = t[0] * R[0] + t[1] * R[1] + t[2] * R[2] + mass * (d1 * d1 + d2 * d2);
+        c[1] = t[3] * R[3] + t[4] * R[4] + t[5] * R[5] + mass * (d0 * d0 + d2 * d2);
+        c[2] = t[6] * R[6] + t[7] * R[7] + t[8] * R[8] + mass * (d0 * d0 + d1 * d1);
+        c[3] = t[0] * R[3] + t[1] * R[4] + t[2] * R[5] - mass * d0 * d1;
+        c[4] = t[0] * R[6] + t[1] * R[7] + t[2] * R[8] - mass * d0 * d2;
+        c[5] = t[3] * R[6] + t[4] * R[7] + t[5] * R[8] - mass * d1 * d2;
+        c[6] = mass * d0; c[7] = mass * d1; c[8] = mass * d2; c[9] = mass;
+      }
+    }
+    // cdof: finalise raw (axis; anchor) -> (axis; axis x (com - anchor))   [mju_dofCom]
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) {
+      const int d = lane + RR_LANES * s;
+      if (d < D.nv) {
+        const int kind = T.dof_i[10 * d + 2], r = T.dof_i[10 * d + 9];
+        float* c = s_cdof + 6 * d;
+        if (kind < 3) {
+          c[0] = c[1] = c[2] = 0;
+          c[3] = kind == 0; c[4] = kind == 1; c[5] = kind == 2;
+        } else {
+          v3 ax = ld3(c);
+          v3 off = get_com(r) - ld3(c + 3);
+          st3(c + 3, cross(ax, off));
+        }
+      }
+    }
+    sync();
+  }
+
+  // ---------------------------------------------------------------- A-6 com_vel + rne forward part (level sweep)
+  __device__ __forceinline__ void velocity_sweep() {
+    for (int L = 1; L <= D.nlevel; ++L) {
+      const int a0 = T.lvl_adr[L], cnt = T.lvl_adr[L + 1] - a0;
+      if (lane < cnt) {
+        const int b = T.lvl_body[a0 + lane];
+        const int* bi = T.body_i + 8 * b;
+        const int p = bi[0], da = bi[3], dn = bi[4];
+        float v[6], a[6];
+        for (int k = 0; k < 6; ++k) { v[k] = s_cvel[6 * p + k]; a[k] = s_cacc[6 * p + k]; }
+        const bool is_free = bi[2] > 0 && T.jnt_i[4 * bi[1]] == 0;
+        if (is_free) {
+          for (int k = 0; k < 3; ++k) {
+            const float qv = s_qvel[da + k];
+            for (int i = 0; i < 6; ++i) v[i] += s_cdof[6 * (da + k) + i] * qv;
+          }
+          float cd[3][6];
+          for (int k = 0; k < 3; ++k) cross_motion(cd[k], v, s_cdof + 6 * (da + 3 + k));
+          for (int k = 0; k < 3; ++k) {
+            const float qv = s_qvel[da + 3 + k];
+            for (int i = 0; i < 6; ++i) v[i] += s_cdof[6 * (da + 3 + k) + i] * qv;
+          }
+          for (int k = 0; k < 3; ++k) {
+            const float qv = s_qvel[da + 3 + k];
+            for (int i = 0; i < 6; ++i) a[i] += cd[k][i] * qv;
+          }
+        } else {
+          for (int k = 0; k < dn; ++k) {
+            float cd[6];
+            cross_motion(cd, v, s_cdof + 6 * (da + k));
+            const float qv = s_qvel[da + k];
+            for (int i = 0; i < 6; ++i) { v[i] += s_cdof[6 * (da + k) + i] * qv; a[i] += cd[i] * qv; }
+          }
+        }
+        float t[6], t1[6], t2[6];
+        mul_inert_vec(t, s_cinert + 10 * b, v);
+        cross_force(t1, v, t);
+        mul_inert_vec(t2, s_cinert + 10 * b, a);
+        for (int k = 0; k < 6; ++k) {
+          s_cvel[6 * b + k] = v[k];
+          s_cacc[6 * b + k] = a[k];
+          s_cfrc[6 * b + k] = t2[k] + t1[k];
+        }
+      }
+      sync();
+    }
+  }
+
+  // ---------------------------------------------------------------- crb + cfrc backward accumulation (level sweep)
+  __device__ __forceinline__ void backward_sweep() {
+    for (int e = lane; e < 10 * D.nbody; e += RR_LANES) s_crb[e] = s_cinert[e];
+    sync();
+    for (int L = D.nlevel - 1; L >= 1; --L) {
+      const int a0 = T.lvl_adr[L], cnt = T.lvl_adr[L + 1] - a0;
+      if (lane < cnt) {
+        const int b = T.lvl_body[a0 + lane];
+        const int ca = T.body_i[8 * b + 6], cn = T.body_i[8 * b + 7];
+        if (cn > 0) {
+          float cr[10], cf[6];
+          for (int k = 0; k < 10; ++k) cr[k] = s_crb[10 * b + k];
+          for (int k = 0; k < 6; ++k) cf[k] = s_cfrc[6 * b + k];
+          for (int ci = cn - 1; ci >= 0; --ci) {  // descending child id = the reference's accumulation order
+            const int c = T.child[ca + ci];
+            for (int k = 0; k < 10; ++k) cr[k] += s_crb[10 * c + k];
+            for (int k = 0; k < 6; ++k) cf[k] += s_cfrc[6 * c + k];
+          }
+          for (int k = 0; k < 10; ++k) s_crb[10 * b + k] = cr[k];
+          for (int k = 0; k < 6; ++k) s_cfrc[6 * b + k] = cf[k];
+        }
+      }
+      sync();
+    }
+  }
+
+  // ---------------------------------------------------------------- A-3 qM (sparse) from crb and cdof
+  __device__ __forceinline__ void mass_matrix() {
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) {
+      const int d = lane + RR_LANES * s;
+      if (d < D.nv) mul_inert_vec(s_buf + 6 * d, s_crb + 10 * T.dof_i[10 * d], s_cdof + 6 * d);
+    }
+    sync();
+    for (int e = lane; e < D.nM; e += RR_LANES) {
+      const int ij = T.M_ij[e], i = ij & 0xffff, j = ij >> 16;
+      float v = dot6(s_cdof + 6 * j, s_buf + 6 * i);
+      if (i == j) v = T.dof_f[16 * i] + v;
+      s_qM[e] = v;
+    }
+    sync();
+  }
+
+  // sparse L'DL in place in s_qLD  [MuJoCo mj_factorM]; damp = dt for the eulerdamp matrix M + dt*diag(damping)
+  __device__ __forceinline__ void factor(float damp) {
+    for (int e = lane; e < D.nM; e += RR_LANES) s_qLD[e] = s_qM[e];
+    sync();
+    if (damp != 0.0f) {
+#pragma unroll
+      for (int s = 0; s < NVS; ++s) {
+        const int d = lane + RR_LANES * s;
+        if (d < D.nv) s_qLD[T.dof_i[10 * d + 4]] += damp * T.dof_f[16 * d + 1];
+      }
+      sync();
+    }
+    for (int k = D.nv - 1; k >= 0; --k) {
+      const int dk = T.dof_i[10 * k + 3];
+      if (dk > 0) {
+        const int Mkk = T.dof_i[10 * k + 4];
+        const float dkk = s_qLD[Mkk];
+        const int npairs = dk * (dk + 1) / 2;
+        for (int t = lane; t < npairs; t += RR_LANES) {
+          const int pq = T.tri[t], p = pq & 255, q = pq >> 8;
+          const float tmp = s_qLD[Mkk + p] / dkk;
+          const int adr = T.M_rowadr[Mkk + p] + (q - p);
+          s_qLD[adr] -= s_qLD[Mkk + q] * tmp;
+        }
+        sync();
+        for (int p = lane + 1; p <= dk; p += RR_LANES) s_qLD[Mkk + p] = s_qLD[Mkk + p] / dkk;
+        sync();
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) {
+      const int d = lane + RR_LANES * s;
+      dinv[s] = d < D.nv ? 1.0f / s_qLD[T.dof_i[10 * d + 4]] : 0.0f;
+    }
+  }
+
+  // x <- (L' D L)^-1 x, level-synchronous  [MuJoCo mj_solveLD]
+  __device__ __forceinline__ void ldl_solve(float* x) {
+    for (int li = 0; li < D.dmax; ++li) {
+      const int level = D.dmax - li;
+#pragma unroll
+      for (int s = 0; s < NVS; ++s) {
+        const int d = lane + RR_LANES * s;
+        if (d < D.nv && dofdepth[s] == level) s_x[d] = x[s];
+      }
+      sync();
+      const int r0 = T.solve_bwd_adr[li], r1 = T.solve_bwd_adr[li + 1];
+      for (int r = r0; r < r1; ++r) {
+#pragma unroll
+        for (int s = 0; s < NVS; ++s) {
+          const int e = T.solve_bwd[r * W + s * RR_LANES + lane];
+          if (e >= 0) x[s] -= s_qLD[e >> 8] * s_x[e & 255];
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) x[s] *= dinv[s];
+    for (int l = 0; l < D.dmax; ++l) {
+#pragma unroll
+      for (int s = 0; s < NVS; ++s) {
+        const int d = lane + RR_LANES * s;
+        if (d < D.nv && dofdepth[s] == l) s_x[d] = x[s];
+      }
+      sync();
+#pragma unroll
+      for (int s = 0; s < NVS; ++s) {
+        const int e = T.solve_fwd[l * W + s * RR_LANES + lane];
+        if (e >= 0) x[s] -= s_qLD[e >> 8] * s_x[e & 255];
+      }
+    }
+    sync();  // s_x may be rewritten by the next call
+  }
+
+  // y = M * s_vec   (s_vec must be visible)
+  __device__ __forceinline__ void mul_m(float* y) {
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) y[s] = 0.0f;
+    for (int t = 0; t < D.T_mulm; ++t) {
+#pragma unroll
+      for (int s = 0; s < NVS; ++s) {
+        const int e = T.mulm[t * W + s * RR_LANES + lane];
+        if (e >= 0) y[s] += s_qM[e >> 8] * s_vec[e & 255];
+      }
+    }
+  }
+
+  __device__ __forceinline__ void put_vec(const float* x) {
+    sync();  // previous readers of s_vec are done
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) {
+      const int d = lane + RR_LANES * s;
+      if (d < D.nv) s_vec[d] = x[s];
+    }
+    sync();
+  }
+
+  // ---------------------------------------------------------------- passive + actuation + qfrc_smooth (per dof)
+  __device__ __forceinline__ void smooth_forces(float* bias_out, float* passive_out) {
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) {
+      const int d = lane + RR_LANES * s;
+      qfrc_smooth[s] = qfrc_actuator[s] = act_dot[s] = 0.0f;
+      bias_out[s] = passive_out[s] = 0.0f;
+      if (d < D.nv) {
+        const int* di = T.dof_i + 10 * d;
+        const float* df = T.dof_f + 16 * d;
+        const float qv = s_qvel[d];
+        float passive = -df[1] * qv;
+        if (di[2] == 6) passive -= df[2] * (s_qpos[di[6]] - df[3]);
+        const float bias = dot6(s_cdof + 6 * d, s_cfrc + 6 * di[0]);
+        float actf = 0.0f;
+        const int u = di[7];
+        if (u >= 0) {
+          const float* af = T.act_f + 8 * u;
+          const float c = fminf(fmaxf(s_ctrl[u], af[5]), af[6]);
+          const float a = s_act[u];
+          act_dot[s] = (c - a) / fmaxf(af[4], RR_MINVAL);
+          actf = af[0] * a + af[1] + af[2] * s_qpos[di[6]] + af[3] * qv;
+        }
+        qfrc_actuator[s] = actf;
+        qfrc_smooth[s] = passive - bias + actf;
+        bias_out[s] = bias; passive_out[s] = passive;
+      }
+    }
+  }
+
+  // ---------------------------------------------------------------- A-4/A-5 collision + constraint rows
+  __device__ __forceinline__ void constraints(float* dbg) {
+    // joint limits
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) {
+      const int d = lane + RR_LANES * s;
+      lim_act[s] = false; lim_sign[s] = 0; lim_D[s] = 0; lim_aref[s] = 0; lim_jar[s] = 0; lim_jv[s] = 0;
+      if (d < D.nv) {
+        const int* di = T.dof_i + 10 * d;
+        if (di[8]) {
+          const float* df = T.dof_f + 16 * d;
+          const float q = s_qpos[di[6]];
+          const float dmin_ = q - df[4], dmax_ = df[5] - q;
+          const float pos = fminf(dmin_, dmax_);
+          if (pos < 0) {
+            float k, b, imp;
+            kbi(D.dt, df[6], df[7], df + 8, pos, k, b, imp);
+            const float r = fmaxf(df[13] * (1.0f - imp) / imp, RR_MINVAL);
+            lim_act[s] = true;
+            lim_sign[s] = dmin_ < dmax_ ? 1.0f : -1.0f;
+            lim_D[s] = 1.0f / r;
+            lim_aref[s] = -b * (lim_sign[s] * s_qvel[d]) - k * imp * pos;
+          }
+          if (dbg) { dbg[D.g_lim + 3 * d] = pos; dbg[D.g_lim + 3 * d + 1] = lim_D[s]; dbg[D.g_lim + 3 * d + 2] = lim_aref[s]; }
+        }
+      }
+    }
+    // contacts
+#pragma unroll
+    for (int cs = 0; cs < NCS; ++cs) {
+      const int c = lane + RR_LANES * cs;
+      con_act[cs] = false; con_mu[cs] = 0; con_D[cs] = 0; con_jadr[cs] = 0; con_nanc[cs] = 0;
+      for (int k = 0; k < 4; ++k) { con_aref[cs][k] = 0; con_jar[cs][k] = 0; con_jv[cs][k] = 0; }
+      if (c < D.ncon) {
+        const int* ci = T.con_i + 8 * c;
+        const float* cf = T.con_f + 26 * c;
+        const int kind = ci[0], b = ci[1], r = ci[2];
+        float gq[4], bq[4], q[4], gm[9];
+        const float* xm = s_xmat + 9 * b;
+        v3 gp = ld3(s_xpos + 3 * b) + mat_vec(xm, ld3(cf));
+        for (int k = 0; k < 4; ++k) { bq[k] = s_xquat[4 * b + k]; gq[k] = cf[3 + k]; }
+        quat_mul(q, bq, gq);
+        quat_to_mat(gm, q);
+        const v3 size = ld3(cf + 7), n = ld3(cf + 10), pp = ld3(cf + 13);
+        v3 fb, pos;
+        float dist;
+        // default tangent from make_frame(n)
+        v3 yb = (n.y > -0.5f && n.y < 0.5f) ? mk3(0, 1, 0) : mk3(0, 0, 1);
+        if (kind == 3) {  // plane - ellipsoid
+          v3 sdir = mk3((gm[0] * n.x + gm[3] * n.y + gm[6] * n.z) * size.x, (gm[1] * n.x + gm[4] * n.y + gm[7] * n.z) * size.y,
+                        (gm[2] * n.x + gm[5] * n.y + gm[8] * n.z) * size.z);
+          const float nn = sqrtf(dot(sdir, sdir));
+          const float inv = nn < RR_MINVAL ? 0.0f : -1.0f / nn;
+          v3 sp = mk3(sdir.x * inv * size.x, sdir.y * inv * size.y, sdir.z * inv * size.z);
+          v3 pt = mat_vec(gm, sp) + gp;
+          dist = dot(n, pt - pp);
+          pos = pt - n * (dist * 0.5f);
+          v3 bb = yb - n * dot(n, yb);
+          fb = bb * (1.0f / sqrtf(dot(bb, bb)));
+        } else {
+          v3 center = gp;
+          const float radius = size.x;
+          if (kind == 0) {
+            v3 bb = yb - n * dot(n, yb);
+            fb = bb * (1.0f / sqrtf(dot(bb, bb)));
+          } else {
+            const v3 axis = mk3(gm[2], gm[5], gm[8]);
+            v3 bb = axis - n * dot(n, axis);
+            const float bn = sqrtf(dot(bb, bb));
+            fb = bn < 0.5f ? yb : bb * (1.0f / bn);
+            center = center + axis * ((kind == 1 ? 1.0f : -1.0f) * size.y);
+          }
+          dist = dot(center - pp, n) - radius;
+          pos = center - n * (radius + 0.5f * dist);
+        }
+        const v3 fc = cross(n, fb);
+        if (dbg) {
+          dbg[D.g_con_dist + c] = dist;
+          st3(dbg + D.g_con_pos + 3 * c, pos);
+          st3(dbg + D.g_con_frame + 9 * c, n); st3(dbg + D.g_con_frame + 9 * c + 3, fb); st3(dbg + D.g_con_frame + 9 * c + 6, fc);
+        }
+        if (dist < 0) {
+          con_act[cs] = true;
+          const float mu = cf[16];
+          float k, bcoef, imp;
+          kbi(D.dt, cf[18], cf[19], cf + 20, dist, k, bcoef, imp);
+          const float rr = fmaxf(cf[17] * (1.0f - imp) / imp, RR_MINVAL);
+          con_mu[cs] = mu; con_D[cs] = 1.0f / rr;
+          const int nanc = ci[4], jadr = ci[5];
+          con_jadr[cs] = jadr; con_nanc[cs] = nanc;
+          const v3 off = pos - get_com(r);
+          float jnv = 0, j1v = 0, j2v = 0;
+          for (int p = 0; p < nanc; ++p) {
+            const int dd = T.con_chain[p * WC + c];
+            const float* cd = s_cdof + 6 * dd;
+            const v3 jp = ld3(cd + 3) + cross(ld3(cd), off);
+            const float jn = dot(n, jp), j1 = dot(fb, jp), j2 = dot(fc, jp);
+            s_J[jadr + 3 * p] = jn; s_J[jadr + 3 * p + 1] = j1; s_J[jadr + 3 * p + 2] = j2;
+            const float qv = s_qvel[dd];
+            jnv += jn * qv; j1v += j1 * qv; j2v += j2 * qv;
+          }
+          const float kk = k * imp * dist;
+          con_aref[cs][0] = -bcoef * (jnv + mu * j1v) - kk;
+          con_aref[cs][1] = -bcoef * (jnv - mu * j1v) - kk;
+          con_aref[cs][2] = -bcoef * (jnv + mu * j2v) - kk;
+          con_aref[cs][3] = -bcoef * (jnv - mu * j2v) - kk;
+        }
+        if (dbg) {
+          dbg[D.g_con_D + c] = con_D[cs];
+          for (int k = 0; k < 4; ++k) dbg[D.g_con_aref + 4 * c + k] = con_aref[cs][k];
+        }
+      }
+      amask[cs] = __ballot(con_act[cs]);
+    }
+    sync();
+  }
+
+  // rows of J * s_vec for this lane's contacts (pyramid rows) ; s_vec visible
+  __device__ __forceinline__ void jac_mul(float (*out)[4]) {
+#pragma unroll
+    for (int cs = 0; cs < NCS; ++cs) {
+      out[cs][0] = out[cs][1] = out[cs][2] = out[cs][3] = 0.0f;
+      if (con_act[cs]) {
+        const int c = lane + RR_LANES * cs;
+        float jn = 0, j1 = 0, j2 = 0;
+        const int jadr = con_jadr[cs];
+        for (int p = 0; p < con_nanc[cs]; ++p) {
+          const float xv = s_vec[T.con_chain[p * WC + c]];
+          jn += s_J[jadr + 3 * p] * xv; j1 += s_J[jadr + 3 * p + 1] * xv; j2 += s_J[jadr + 3 * p + 2] * xv;
+        }
+        const float mu = con_mu[cs];
+        out[cs][0] = jn + mu * j1; out[cs][1] = jn - mu * j1; out[cs][2] = jn + mu * j2; out[cs][3] = jn - mu * j2;
+      }
+    }
+  }
+
+  // constraint state at the current Jaref: forces, qfrc_constraint, cost  [UP mjx solver._update_constraint]
+  __device__ __forceinline__ void update_constraint() {
+    float part[2] = {0.0f, 0.0f};  // [0] = sum D*Jaref^2 over active rows, [1] = gauss dot
+#pragma unroll
+    for (int cs = 0; cs < NCS; ++cs) {
+      const int c = lane + RR_LANES * cs;
+      if (c < D.ncon) {
+        float f[4] = {0, 0, 0, 0};
+        if (con_act[cs]) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float jr = con_jar[cs][k];
+            if (jr < 0) { f[k] = -con_D[cs] * jr; part[0] += con_D[cs] * jr * jr; }
+          }
+        }
+        const float mu = con_mu[cs];
+        s_cf[3 * c] = f[0] + f[1] + f[2] + f[3];
+        s_cf[3 * c + 1] = mu * (f[0] - f[1]);
+        s_cf[3 * c + 2] = mu * (f[2] - f[3]);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) {
+      qfrc_con[s] = 0.0f;
+      if (lim_act[s] && lim_jar[s] < 0) {
+        const float f = -lim_D[s] * lim_jar[s];
+        part[0] += lim_D[s] * lim_jar[s] * lim_jar[s];
+        qfrc_con[s] = lim_sign[s] * f;
+      }
+      part[1] += (Ma[s] - qfrc_smooth[s]) * (qacc[s] - qacc_smooth[s]);
+    }
+    sync();
+    for (int t = 0; t < D.T_jtf; ++t) {
+#pragma unroll
+      for (int s = 0; s < NVS; ++s) {
+        const int e = T.jtf[t * W + s * RR_LANES + lane];
+        if (e >= 0) {
+          const int c = e & 255, adr = e >> 8;
+          if (con_bit(c))
+            qfrc_con[s] += s_J[adr] * s_cf[3 * c] + s_J[adr + 1] * s_cf[3 * c + 1] + s_J[adr + 2] * s_cf[3 * c + 2];
+        }
+      }
+    }
+    wave_sum_n<2>(part);
+    gauss = 0.5f * part[1];
+    prev_cost = cost;
+    cost = 0.5f * part[0] + gauss;
+  }
+
+  __device__ __forceinline__ void update_gradient() {
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) { grad[s] = Ma[s] - qfrc_smooth[s] - qfrc_con[s]; Mgrad[s] = grad[s]; }
+    ldl_solve(Mgrad);
+  }
+
+  // [UP mjx solver._Context.create]: Jaref, Ma, constraint state (and gradient/search) at `qacc`
+  __device__ __forceinline__ void ctx_create(bool with_grad) {
+    put_vec(qacc);
+    jac_mul(con_jar);
+#pragma unroll
+    for (int cs = 0; cs < NCS; ++cs)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) con_jar[cs][k] -= con_aref[cs][k];
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) lim_jar[s] = lim_sign[s] * qacc[s] - lim_aref[s];
+    mul_m(Ma);
+    cost = INFINITY; prev_cost = 0.0f;
+    update_constraint();
+    if (with_grad) {
+      update_gradient();
+#pragma unroll
+      for (int s = 0; s < NVS; ++s) search[s] = -Mgrad[s];
+    }
+  }
+
+  // line-search point(s): cost and derivatives of the piecewise-quadratic 1-D cost at alpha
+  template <int NP>
+  __device__ __forceinline__ void ls_eval(const float* alpha, const float* qg, LSPoint* out) {
+    float q[3 * NP];
+#pragma unroll
+    for (int i = 0; i < 3 * NP; ++i) q[i] = 0.0f;
+#pragma unroll
+    for (int cs = 0; cs < NCS; ++cs) {
+      if (con_act[cs]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float jr = con_jar[cs][k], jv = con_jv[cs][k], Dv = con_D[cs];
+          const float q0 = 0.5f * jr * jr * Dv, q1 = jv * jr * Dv, q2 = 0.5f * jv * jv * Dv;
+#pragma unroll
+          for (int i = 0; i < NP; ++i)
+            if (jr + alpha[i] * jv < 0) { q[3 * i] += q0; q[3 * i + 1] += q1; q[3 * i + 2] += q2; }
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) {
+      if (lim_act[s]) {
+        const float jr = lim_jar[s], jv = lim_jv[s], Dv = lim_D[s];
+        const float q0 = 0.5f * jr * jr * Dv, q1 = jv * jr * Dv, q2 = 0.5f * jv * jv * Dv;
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+          if (jr + alpha[i] * jv < 0) { q[3 * i] += q0; q[3 * i + 1] += q1; q[3 * i + 2] += q2; }
+      }
+    }
+    wave_sum_n<3 * NP>(q);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const float q0 = qg[0] + q[3 * i], q1 = qg[1] + q[3 * i + 1], q2 = qg[2] + q[3 * i + 2];
+      const float a = alpha[i];
+      out[i].alpha = a;
+      out[i].cost = a * a * q2 + a * q1 + q0;
+      out[i].d0 = 2.0f * a * q2 + q1;
+      out[i].d1 = 2.0f * q2 + (q2 == 0.0f ? RR_MINVAL : 0.0f);
+    }
+  }
+
+  // [UP mjx solver._linesearch]
+  __device__ __forceinline__ void linesearch() {
+    float red[4] = {0, 0, 0, 0};
+    put_vec(search);
+    mul_m(mv);
+    jac_mul(con_jv);
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) {
+      lim_jv[s] = lim_sign[s] * search[s];
+      red[0] += search[s] * search[s];
+      red[1] += search[s] * Ma[s];
+      red[2] += search[s] * qfrc_smooth[s];
+      red[3] += search[s] * mv[s];
+    }
+    wave_sum_n<4>(red);
+    const float smag = sqrtf(red[0]) * D.meaninertia * (float)(D.nv > 1 ? D.nv : 1);
+    const float gtol = D.tolerance * D.ls_tolerance * smag;
+    const float qg[3] = {gauss, red[1] - red[2], 0.5f * red[3]};
+    LSPoint p0, lo, hi, tmp3[3];
+    float a1[1] = {0.0f};
+    ls_eval<1>(a1, qg, &p0);
+    a1[0] = p0.alpha - p0.d0 / p0.d1;
+    ls_eval<1>(a1, qg, &lo);
+    if (lo.d0 < p0.d0) { hi = p0; } else { hi = lo; lo = p0; }
+    bool swap = true;
+    for (int it = 0; it < D.ls_iterations; ++it) {
+      bool done = !swap;
+      done |= (lo.d0 < 0) && (lo.d0 > -gtol);
+      done |= (hi.d0 > 0) && (hi.d0 < gtol);
+      if (uni(done)) break;
+      const float a3[3] = {lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, 0.5f * (lo.alpha + hi.alpha)};
+      ls_eval<3>(a3, qg, tmp3);
+      const LSPoint lo_next = tmp3[0], hi_next = tmp3[1], mid = tmp3[2];
+      const bool swap_lo_next = (lo.d0 > 0) || (lo.d0 < lo_next.d0);
+      if (swap_lo_next) lo = lo_next;
+      const bool swap_lo_mid = (mid.d0 < 0) && (lo.d0 < mid.d0);
+      if (swap_lo_mid) lo = mid;
+      const bool swap_hi_next = (hi.d0 < 0) || (hi.d0 > hi_next.d0);
+      if (swap_hi_next) hi = hi_next;
+      const bool swap_hi_mid = (mid.d0 > 0) && (hi.d0 > mid.d0);
+      if (swap_hi_mid) hi = mid;
+      swap = swap_lo_next || swap_lo_mid || swap_hi_next || swap_hi_mid;
+    }
+    const bool improved = uni((lo.cost < p0.cost) || (hi.cost < p0.cost));
+    const float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
+    if (improved) {
+#pragma unroll
+      for (int s = 0; s < NVS; ++s) { qacc[s] += search[s] * alpha; Ma[s] += mv[s] * alpha; lim_jar[s] += lim_jv[s] * alpha; }
+#pragma unroll
+      for (int cs = 0; cs < NCS; ++cs)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) con_jar[cs][k] += con_jv[cs][k] * alpha;
+    }
+  }
+
+  // [UP mjx solver.solve] primal CG with warm start; returns the iteration count
+  __device__ __forceinline__ int solve() {
+    const float scale = 1.0f / (D.meaninertia * (float)(D.nv > 1 ? D.nv : 1));
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) qacc[s] = qacc_smooth[s];
+    ctx_create(false);
+    const float cost_smooth = cost;
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) qacc[s] = warm[s];
+    ctx_create(false);
+    if (uni(!(cost < cost_smooth))) {
+#pragma unroll
+      for (int s = 0; s < NVS; ++s) qacc[s] = qacc_smooth[s];
+    }
+    ctx_create(true);
+    int niter = 0;
+    while (true) {
+      const float improvement = (prev_cost - cost) * scale;
+      float g2 = 0.0f;
+#pragma unroll
+      for (int s = 0; s < NVS; ++s) g2 += grad[s] * grad[s];
+      const float gradient = sqrtf(wave_sum(g2)) * scale;
+      bool done = niter >= D.iterations;
+      done |= improvement < D.tolerance;
+      done |= gradient < D.tolerance;
+      if (uni(done)) break;
+      linesearch();
+      float pm[NVS], gg = 0.0f;
+#pragma unroll
+      for (int s = 0; s < NVS; ++s) { gg += grad[s] * Mgrad[s]; pm[s] = Mgrad[s]; }
+      update_constraint();
+      update_gradient();
+      float bt[2] = {0.0f, gg};
+#pragma unroll
+      for (int s = 0; s < NVS; ++s) bt[0] += grad[s] * (Mgrad[s] - pm[s]);
+      wave_sum_n<2>(bt);
+      const float beta = fmaxf(0.0f, bt[0] / fmaxf(RR_MINVAL, bt[1]));
+#pragma unroll
+      for (int s = 0; s < NVS; ++s) search[s] = -Mgrad[s] + beta * search[s];
+      ++niter;
+    }
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) warm[s] = qacc[s];
+    return niter;
+  }
+
+  // ---------------------------------------------------------------- A-8 euler (+eulerdamp) and position integration
+  __device__ __forceinline__ void euler() {
+    factor(D.dt);
+    float qa[NVS];
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) qa[s] = qfrc_smooth[s] + qfrc_con[s];
+    ldl_solve(qa);
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) {
+      const int d = lane + RR_LANES * s;
+      if (d < D.nv) {
+        const int u = T.dof_i[10 * d + 7];
+        if (u >= 0) s_act[u] += D.dt * act_dot[s];
+        s_qvel[d] += D.dt * qa[s];
+      }
+    }
+    sync();
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) {
+      const int d = lane + RR_LANES * s;
+      if (d < D.nv) {
+        const int kind = T.dof_i[10 * d + 2], qadr = T.dof_i[10 * d + 6];
+        if (kind == 6 || kind < 3) {
+          s_qpos[qadr] += D.dt * s_qvel[d];
+        } else if (kind == 3) {  // quaternion of the free joint: q <- normalize(q * exp(dt*w/2)), w in the body frame
+          const v3 w = ld3(s_qvel + d);
+          const float n = sqrtf(dot(w, w));
+          v3 ax = mk3(0, 0, 0);
+          if (n > RR_MINVAL) ax = w * (1.0f / n);
+          const float ang = D.dt * n, sn = sinf(ang * 0.5f), cs = cosf(ang * 0.5f);
+          float qr[4] = {cs, ax.x * sn, ax.y * sn, ax.z * sn}, q0[4], qn[4];
+          for (int k = 0; k < 4; ++k) q0[k] = s_qpos[qadr + k];
+          quat_mul(qn, q0, qr);
+          quat_normalize(qn);
+          for (int k = 0; k < 4; ++k) s_qpos[qadr + k] = qn[k];
+        }
+      }
+    }
+    sync();
+  }
+};
+
+// ------------------------------------------------------------------------------------------ kernel
+template <int NBS, int NVS, int NCS>
+__global__ __launch_bounds__(RR_LANES) void rr_step_kernel(const RRDims D, const RRTables T, const RRIO io, const int num_envs,
+                                                           const int n_frames) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int env = blockIdx.x;
+  if (env >= num_envs) return;
+  Wave<NBS, NVS, NCS> w(D, T, lds);
+  const int lane = threadIdx.x;
+  float* dbg = io.dbg ? io.dbg + (size_t)env * D.dbg_floats : nullptr;
+
+  // ---- load state
+  for (int i = lane; i < D.nq; i += RR_LANES) w.s_qpos[i] = io.qpos[(size_t)env * D.nq + i];
+  for (int i = lane; i < D.nv; i += RR_LANES) w.s_qvel[i] = io.qvel[(size_t)env * D.nv + i];
+  for (int i = lane; i < D.nu; i += RR_LANES) {
+    w.s_act[i] = io.act[(size_t)env * D.nu + i];
+    w.s_ctrl[i] = io.ctrl ? io.ctrl[(size_t)env * D.nu + i] : 0.0f;
+  }
+#pragma unroll
+  for (int s = 0; s < NVS; ++s) {
+    const int d = lane + RR_LANES * s;
+    w.warm[s] = d < D.nv ? io.warm[(size_t)env * D.nv + d] : 0.0f;
+    w.dofdepth[s] = d < D.nv ? T.dof_i[10 * d + 3] : -1;
+    w.qacc[s] = w.Ma[s] = w.grad[s] = w.Mgrad[s] = w.search[s] = w.mv[s] = w.qfrc_con[s] = 0.0f;
+  }
+  if (lane == 0) {  // world body
+    for (int k = 0; k < 3; ++k) w.s_xpos[k] = 0.0f;
+    w.s_xquat[0] = 1.0f; w.s_xquat[1] = w.s_xquat[2] = w.s_xquat[3] = 0.0f;
+    for (int k = 0; k < 9; ++k) w.s_xmat[k] = (k % 4 == 0) ? 1.0f : 0.0f;
+    for (int k = 0; k < 6; ++k) { w.s_cvel[k] = 0.0f; w.s_cfrc[k] = 0.0f; }
+    w.s_cacc[0] = w.s_cacc[1] = w.s_cacc[2] = 0.0f;
+    w.s_cacc[3] = -D.gx; w.s_cacc[4] = -D.gy; w.s_cacc[5] = -D.gz;
+    for (int k = 0; k < 10; ++k) w.s_cinert[k] = 0.0f;
+  }
+  w.sync();
+
+  const int frames = (io.mode & 1) ? n_frames : 1;
+  int niter = 0;
+  for (int f = 0; f < frames; ++f) {
+    float* dg = (f == frames - 1) ? dbg : nullptr;
+    float bias[NVS], passive[NVS];
+    w.kinematics();
+    w.com_pos();
+    w.velocity_sweep();
+    w.backward_sweep();
+    w.mass_matrix();
+    w.factor(0.0f);
+    w.smooth_forces(bias, passive);
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) w.qacc_smooth[s] = w.qfrc_smooth[s];
+    w.ldl_solve(w.qacc_smooth);
+    if (dg) {  // dump before the solver / integrator reuse buffers
+      for (int e = lane; e < 3 * D.nbody; e += RR_LANES) dg[D.g_xpos + e] = w.s_xpos[e];
+      for (int e = lane; e < 4 * D.nbody; e += RR_LANES) dg[D.g_xquat + e] = w.s_xquat[e];
+      for (int e = lane; e < 9 * D.nbody; e += RR_LANES) dg[D.g_xmat + e] = w.s_xmat[e];
+      for (int e = lane; e < 10 * D.nbody; e += RR_LANES) { dg[D.g_cinert + e] = w.s_cinert[e]; dg[D.g_crb + e] = w.s_crb[e]; }
+      for (int e = lane; e < 6 * D.nv; e += RR_LANES) dg[D.g_cdof + e] = w.s_cdof[e];
+      for (int e = lane; e < 6 * D.nbody; e += RR_LANES) { dg[D.g_cvel + e] = w.s_cvel[e]; dg[D.g_cfrc + e] = w.s_cfrc[e]; }
+      for (int e = lane; e < D.nM; e += RR_LANES) { dg[D.g_qM + e] = w.s_qM[e]; dg[D.g_qLD + e] = w.s_qLD[e]; }
+      if (lane == 0) { for (int k = 0; k < 3; ++k) { dg[D.g_com + k] = w.com0[k]; dg[D.g_com + 3 + k] = w.com1[k]; } }
+#pragma unroll
+      for (int s = 0; s < NVS; ++s) {
+        const int d = lane + RR_LANES * s;
+        if (d < D.nv) {
+          dg[D.g_dinv + d] = w.dinv[s]; dg[D.g_bias + d] = bias[s]; dg[D.g_passive + d] = passive[s];
+          dg[D.g_actuator + d] = w.qfrc_actuator[s]; dg[D.g_smooth + d] = w.qfrc_smooth[s];
+          dg[D.g_qacc_smooth + d] = w.qacc_smooth[s];
+        }
+      }
+    }
+    w.constraints(dg);
+    niter = w.solve();
+    if (dg) {
+#pragma unroll
+      for (int s = 0; s < NVS; ++s) {
+        const int d = lane + RR_LANES * s;
+        if (d < D.nv) { dg[D.g_qacc + d] = w.qacc[s]; dg[D.g_qfrc_constraint + d] = w.qfrc_con[s]; }
+      }
+      for (int e = lane; e < D.nJ; e += RR_LANES) dg[D.g_J + e] = w.s_J[e];
+      if (lane == 0) { dg[D.g_misc] = (float)niter; dg[D.g_misc + 1] = w.cost; }
+    }
+    if (io.mode & 1) w.euler();
+  }
+
+  // ---- write back state
+  for (int i = lane; i < D.nq; i += RR_LANES) io.qpos[(size_t)env * D.nq + i] = w.s_qpos[i];
+  for (int i = lane; i < D.nv; i += RR_LANES) io.qvel[(size_t)env * D.nv + i] = w.s_qvel[i];
+  for (int i = lane; i < D.nu; i += RR_LANES) io.act[(size_t)env * D.nu + i] = w.s_act[i];
+#pragma unroll
+  for (int s = 0; s < NVS; ++s) {
+    const int d = lane + RR_LANES * s;
+    if (d < D.nv) {
+      io.warm[(size_t)env * D.nv + d] = w.warm[s];
+      if (io.o_qfrc_actuator) io.o_qfrc_actuator[(size_t)env * D.nv + d] = w.qfrc_actuator[s];
+    }
+  }
+  if (io.o_cinert) for (int e = lane; e < 10 * D.nbody; e += RR_LANES) io.o_cinert[(size_t)env * 10 * D.nbody + e] = w.s_cinert[e];
+  if (io.o_cvel) for (int e = lane; e < 6 * D.nbody; e += RR_LANES) io.o_cvel[(size_t)env * 6 * D.nbody + e] = w.s_cvel[e];
+  if (io.o_xpos) for (int e = lane; e < 3 * D.nbody; e += RR_LANES) io.o_xpos[(size_t)env * 3 * D.nbody + e] = w.s_xpos[e];
+  if (io.o_xmat) for (int e = lane; e < 9 * D.nbody; e += RR_LANES) io.o_xmat[(size_t)env * 9 * D.nbody + e] = w.s_xmat[e];
+  if (io.o_com && lane == 0) for (int k = 0; k < 3; ++k) io.o_com[(size_t)env * 3 + k] = w.com0[k];
+
+  // ---- reference env epilogue [REF Rodent_Env_Brax.py:103-158]
+  if (io.obs) {
+    const bool is_reset = (io.mode & 2) != 0;
+    const int old_frame = io.cur_frame[env];
+    const int new_frame = is_reset ? old_frame : old_frame + 1;
+    float* ob = io.obs + (size_t)env * D.obs_dim;
+    int o = 0;
+    for (int i = lane; i < D.nq; i += RR_LANES) ob[o + i] = w.s_qpos[i];
+    o += D.nq;
+    for (int i = lane; i < D.nv; i += RR_LANES) ob[o + i] = w.s_qvel[i];
+    o += D.nv;
+    for (int i = lane; i < 10 * (D.nbody - 1); i += RR_LANES) ob[o + i] = w.s_cinert[10 + i];
+    o += 10 * (D.nbody - 1);
+    for (int i = lane; i < 6 * (D.nbody - 1); i += RR_LANES) ob[o + i] = w.s_cvel[6 + i];
+    o += 6 * (D.nbody - 1);
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) {
+      const int d = lane + RR_LANES * s;
+      if (d < D.nv) ob[o + d] = w.qfrc_actuator[s];
+    }
+    o += D.nv;
+    if (lane < 3) {  // xmat[1] @ (track_pos[frame + 1] - qpos[:3]); JAX clamps the gather index
+      int fi = new_frame + 1;
+      fi = fi < 0 ? 0 : (fi > io.track_len - 1 ? io.track_len - 1 : fi);
+      const v3 v = ld3(io.track_pos + 3 * fi) - ld3(w.s_qpos);
+      const float* xm = w.s_xmat + 9 + 3 * lane;
+      ob[o + lane] = xm[0] * v.x + xm[1] * v.y + xm[2] * v.z;
+    }
+    if (!is_reset) {
+      float a2 = 0.0f;
+      for (int i = lane; i < D.nu; i += RR_LANES) { const float a = io.ctrl[(size_t)env * D.nu + i]; a2 += a * a; }
+      a2 = wave_sum(a2);
+      if (lane == 0) {
+        int fi = old_frame < 0 ? 0 : (old_frame > io.track_len - 1 ? io.track_len - 1 : old_frame);
+        const v3 dx = ld3(w.s_qpos) - ld3(io.track_pos + 3 * fi);
+        const float pos_reward = expf(-100.0f * sqrtf(dot(dx, dx)));
+        const float z = w.s_qpos[2];
+        float healthy = z < io.z_min ? 0.0f : 1.0f;
+        if (z > io.z_max) healthy = 0.0f;
+        const float hr = io.terminate_when_unhealthy ? io.healthy_reward : io.healthy_reward * healthy;
+        const float cc = io.ctrl_cost_weight * a2;
+        io.reward[env] = pos_reward + hr - cc;
+        io.done[env] = io.terminate_when_unhealthy ? 1.0f - healthy : 0.0f;
+        io.metrics[3 * env] = pos_reward; io.metrics[3 * env + 1] = -cc; io.metrics[3 * env + 2] = hr;
+        io.cur_frame[env] = new_frame;
+      }
+    }
+  }
+}

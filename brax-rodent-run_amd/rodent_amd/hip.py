@@ -1,0 +1,207 @@
+"""ctypes binding of librodent_hip.so (C ABI: include/rodent_rr.h).
+
+PyTorch is used only for device memory and streams: every tensor handed to the library is a
+contiguous float32 / int32 CUDA(HIP) tensor whose `data_ptr()` crosses the ABI.  There is no CPU
+fallback: if the shared library is missing or no GPU is present the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "librodent_hip.so")
+
+
+class RRDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nM", "ncon", "nlimit",
+                                         "nefc", "obs_dim", "iterations", "ls_iterations", "lds_bytes", "dbg_floats")] \
+        + [("timestep", C.c_float)]
+
+
+class RRState(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("qpos", "qvel", "act", "qacc_warmstart")]
+
+
+class RROutputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("cinert", "cvel", "qfrc_actuator", "xpos", "xmat", "subtree_com", "debug")]
+
+
+class RREnvIO(C.Structure):
+    _fields_ = [("track_pos", C.c_void_p), ("track_len", C.c_int32), ("cur_frame", C.c_void_p), ("obs", C.c_void_p),
+                ("reward", C.c_void_p), ("done", C.c_void_p), ("metrics", C.c_void_p), ("healthy_reward", C.c_float),
+                ("ctrl_cost_weight", C.c_float), ("healthy_z_min", C.c_float), ("healthy_z_max", C.c_float),
+                ("terminate_when_unhealthy", C.c_int32)]
+
+
+EXPORTS = ["rr_model_load", "rr_model_dims", "rr_model_set_solver", "rr_model_destroy", "rr_batch_create",
+           "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset",
+           "rr_debug_layout", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
+
+_lib = None
+
+
+def lib():
+    """Load librodent_hip.so (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(LIB_PATH)
+        L.rr_last_error.restype = C.c_char_p
+        L.rr_model_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.rr_model_dims.argtypes = [C.c_void_p, C.POINTER(RRDims)]
+        L.rr_model_set_solver.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        L.rr_model_destroy.argtypes = [C.c_void_p]
+        L.rr_model_destroy.restype = None
+        L.rr_batch_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.rr_batch_destroy.argtypes = [C.c_void_p]
+        L.rr_batch_destroy.restype = None
+        L.rr_pipeline_init.argtypes = [C.c_void_p, C.POINTER(RRState), C.POINTER(RROutputs)]
+        L.rr_pipeline_step.argtypes = [C.c_void_p, C.POINTER(RRState), C.c_void_p, C.c_int32, C.POINTER(RROutputs)]
+        L.rr_env_step.argtypes = [C.c_void_p, C.POINTER(RRState), C.c_void_p, C.c_int32, C.POINTER(RREnvIO),
+                                  C.POINTER(RROutputs)]
+        L.rr_env_reset.argtypes = [C.c_void_p, C.POINTER(RRState), C.POINTER(RREnvIO), C.POINTER(RROutputs)]
+        L.rr_debug_layout.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_int32)),
+                                      C.POINTER(C.POINTER(C.c_int32))]
+        L.rr_batch_set_timing.argtypes = [C.c_void_p, C.c_int32]
+        L.rr_batch_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise RuntimeError(f"librodent_hip: {lib().rr_last_error().decode()} (status {rc})")
+    return rc
+
+
+def _ptr(t: Optional[torch.Tensor], dtype=torch.float32, numel: Optional[int] = None):
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise ValueError(f"expected a contiguous {dtype} device tensor, got {t.dtype} on {t.device}")
+    if numel is not None and t.numel() != numel:
+        raise ValueError(f"tensor has {t.numel()} elements, expected {numel}")
+    return t.data_ptr()
+
+
+class Model:
+    """A compiled model loaded from an RRM1 blob (host side)."""
+
+    def __init__(self, blob_path: str, iterations: Optional[int] = None, ls_iterations: Optional[int] = None):
+        self.h = C.c_void_p()
+        _check(lib().rr_model_load(blob_path.encode(), C.byref(self.h)))
+        if iterations is not None:
+            d = self.dims
+            _check(lib().rr_model_set_solver(self.h, iterations, ls_iterations if ls_iterations is not None else d.ls_iterations))
+
+    @property
+    def dims(self) -> RRDims:
+        d = RRDims()
+        _check(lib().rr_model_dims(self.h, C.byref(d)))
+        return d
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().rr_model_destroy(self.h)
+        except Exception:
+            pass
+
+
+class Batch:
+    """`num_envs` environments of one model on one GPU; all work goes to torch's current stream."""
+
+    def __init__(self, model: Model, num_envs: int, device: Optional[torch.device] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("rodent_amd.hip.Batch needs a GPU (no CPU fallback)")
+        self.model = model
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.N = int(num_envs)
+        self.dims = model.dims
+        self.h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream().cuda_stream
+        _check(lib().rr_batch_create(model.h, self.N, self.device.index or 0, C.c_void_p(stream), C.byref(self.h)))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().rr_batch_destroy(self.h)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def zeros_state(self) -> Dict[str, torch.Tensor]:
+        d, N, dev = self.dims, self.N, self.device
+        return dict(qpos=torch.zeros(N, d.nq, device=dev), qvel=torch.zeros(N, d.nv, device=dev),
+                    act=torch.zeros(N, d.na, device=dev), qacc_warmstart=torch.zeros(N, d.nv, device=dev))
+
+    def _state(self, st) -> RRState:
+        d, N = self.dims, self.N
+        return RRState(_ptr(st["qpos"], numel=N * d.nq), _ptr(st["qvel"], numel=N * d.nv),
+                       _ptr(st["act"], numel=N * d.na), _ptr(st["qacc_warmstart"], numel=N * d.nv))
+
+    def _outputs(self, out) -> Optional[RROutputs]:
+        if not out:
+            return None
+        d, N = self.dims, self.N
+        sizes = dict(cinert=10 * d.nbody, cvel=6 * d.nbody, qfrc_actuator=d.nv, xpos=3 * d.nbody, xmat=9 * d.nbody,
+                     subtree_com=3, debug=d.dbg_floats)
+        o = RROutputs()
+        for k, w in sizes.items():
+            setattr(o, k, _ptr(out.get(k), numel=N * w) if out.get(k) is not None else None)
+        return o
+
+    def _env(self, env) -> RREnvIO:
+        d, N = self.dims, self.N
+        tp = env["track_pos"]
+        e = RREnvIO()
+        e.track_pos = _ptr(tp)
+        e.track_len = tp.shape[0]
+        e.cur_frame = _ptr(env["cur_frame"], torch.int32, N)
+        e.obs = _ptr(env["obs"], numel=N * d.obs_dim)
+        e.reward = _ptr(env.get("reward"), numel=N) if env.get("reward") is not None else None
+        e.done = _ptr(env.get("done"), numel=N) if env.get("done") is not None else None
+        e.metrics = _ptr(env.get("metrics"), numel=3 * N) if env.get("metrics") is not None else None
+        e.healthy_reward = env.get("healthy_reward", 1.0)
+        e.ctrl_cost_weight = env.get("ctrl_cost_weight", 0.1)
+        e.healthy_z_min, e.healthy_z_max = env.get("healthy_z_range", (0.03, 0.5))
+        e.terminate_when_unhealthy = int(env.get("terminate_when_unhealthy", True))
+        return e
+
+    # ------------------------------------------------------------------ C-ABI calls
+    def pipeline_init(self, st, out=None):
+        o = self._outputs(out)
+        _check(lib().rr_pipeline_init(self.h, C.byref(self._state(st)), C.byref(o) if o else None))
+
+    def pipeline_step(self, st, ctrl, n_frames: int, out=None):
+        o = self._outputs(out)
+        _check(lib().rr_pipeline_step(self.h, C.byref(self._state(st)), _ptr(ctrl, numel=self.N * self.dims.nu),
+                                      int(n_frames), C.byref(o) if o else None))
+
+    def env_step(self, st, action, n_frames: int, env, out=None):
+        o = self._outputs(out)
+        _check(lib().rr_env_step(self.h, C.byref(self._state(st)), _ptr(action, numel=self.N * self.dims.nu),
+                                 int(n_frames), C.byref(self._env(env)), C.byref(o) if o else None))
+
+    def env_reset(self, st, env, out=None):
+        o = self._outputs(out)
+        _check(lib().rr_env_reset(self.h, C.byref(self._state(st)), C.byref(self._env(env)), C.byref(o) if o else None))
+
+    def debug_layout(self):
+        names, offs, sizes = C.POINTER(C.c_char_p)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
+        n = _check(lib().rr_debug_layout(self.h, C.byref(names), C.byref(offs), C.byref(sizes)))
+        return {names[i].decode(): (offs[i], sizes[i]) for i in range(n)}
+
+    def set_timing(self, enable: bool):
+        _check(lib().rr_batch_set_timing(self.h, int(enable)))
+
+    def kernel_time(self):
+        ms, n = C.c_double(), C.c_int64()
+        _check(lib().rr_batch_kernel_time(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -1,0 +1,205 @@
+"""Kernel schedule tables: lane-major index tables for the one-wave-per-env HIP step kernel.
+
+The fused step kernel (csrc/rr_step.hip) runs one 64-lane wavefront per environment.  All of
+its irregular access patterns (kinematic-tree level sweeps, sparse L'DL factor/solve, sparse
+M*x, contact-Jacobian transpose products) are driven by static index tables computed here once
+per model and stored in the model blob as `k_*` arrays.  Tables indexed by a loop iteration `t`
+and a lane are laid out `[t][slot*64 + lane]` so one wave-load is a single coalesced 256-byte
+read.  `slot` handles per-env element counts above 64 (dof d lives at lane d%64, slot d//64).
+
+Packed entry format (int32): low 8 bits = element index, upper bits = LDS address offset,
+-1 = no entry.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+LANES = 64
+
+
+def _slots(n):
+    return max(1, (int(n) + LANES - 1) // LANES)
+
+
+def build_kernel_tables(m):
+    nb, nv, njnt, nM = int(m["nbody"]), int(m["nv"]), int(m["njnt"]), int(m["nM"])
+    ncon = int(m["ncon"])
+    par = m["body_parentid"]
+    dpar = m["dof_parentid"]
+    Madr = m["dof_Madr"]
+    ddepth = m["dof_depth"]
+    NBS, NVS, NCS = _slots(nb), _slots(nv), _slots(ncon)
+    k = {}
+    k["k_slots"] = np.array([NBS, NVS, NCS], np.int32)
+
+    # ---- body levels (level 1 = children of world) and child lists
+    depth = m["body_depth"]
+    nlevel = int(depth.max())
+    order = sorted(range(1, nb), key=lambda b: (depth[b], b))
+    lvl_adr = np.zeros(nlevel + 2, np.int32)
+    for L in range(1, nlevel + 1):
+        lvl_adr[L + 1] = lvl_adr[L] + sum(1 for b in order if depth[b] == L)
+    if max(lvl_adr[L + 1] - lvl_adr[L] for L in range(1, nlevel + 1)) > LANES:
+        raise ValueError("more than 64 bodies on one tree level")
+    k["k_lvl_adr"] = lvl_adr
+    k["k_lvl_body"] = np.asarray(order, np.int32)
+    child_adr = np.zeros(nb + 1, np.int32)
+    child = []
+    for b in range(nb):
+        child_adr[b] = len(child)
+        child += [c for c in range(1, nb) if par[c] == b]
+    child_adr[nb] = len(child)
+    k["k_child_adr"] = child_adr
+    k["k_child"] = np.asarray(child, np.int32)
+    # roots (kinematic trees) and their total mass
+    roots = sorted(set(int(r) for r in m["body_rootid"][1:]))
+    k["k_root"] = np.asarray(roots, np.int32)
+    k["k_root_mass"] = np.asarray([m["body_subtreemass"][r] for r in roots], np.float64)
+    root_index = {r: i for i, r in enumerate(roots)}
+    k["k_body_root"] = np.asarray([root_index.get(int(r), 0) for r in m["body_rootid"]], np.int32)
+
+    # ---- packed per-body / per-joint / per-dof parameter rows
+    k["k_body_i"] = np.stack([par, m["body_jntadr"], m["body_jntnum"], m["body_dofadr"], m["body_dofnum"],
+                              k["k_body_root"], child_adr[:-1], child_adr[1:] - child_adr[:-1]], axis=1).astype(np.int32)
+    k["k_body_f"] = np.concatenate([m["body_pos"], m["body_quat"], m["body_ipos"], m["body_iquat"],
+                                    m["body_mass"][:, None], m["body_inertia"]], axis=1)  # 18 floats
+    qa = m["jnt_qposadr"]
+    k["k_jnt_i"] = np.stack([m["jnt_type"], qa, m["jnt_dofadr"], m["jnt_bodyid"]], axis=1).astype(np.int32)
+    k["k_jnt_f"] = np.concatenate([m["jnt_pos"], m["jnt_axis"], m["qpos0"][qa][:, None],
+                                   np.zeros((njnt, 1))], axis=1)  # 8 floats
+    # per dof: kind 0-2 free translation x/y/z, 3-5 free rotation x/y/z, 6 hinge
+    kind = np.zeros(nv, np.int32)
+    dof_qposadr = np.zeros(nv, np.int32)
+    act_of_dof = np.full(nv, -1, np.int32)
+    for d in range(nv):
+        j = m["dof_jntid"][d]
+        if m["jnt_type"][j] == 0:
+            kind[d] = d - m["jnt_dofadr"][j]
+            dof_qposadr[d] = m["jnt_qposadr"][j] + kind[d]     # translation: qpos index; rotation: unused
+        else:
+            kind[d] = 6
+            dof_qposadr[d] = m["jnt_qposadr"][j]
+    for u in range(int(m["nu"])):
+        d = m["actuator_dofadr"][u]
+        if act_of_dof[d] >= 0:
+            raise ValueError("two actuators on one dof are not supported")
+        act_of_dof[d] = u
+    lim = np.zeros(nv, np.int32)
+    for j in range(njnt):
+        if m["jnt_limited"][j]:
+            lim[m["jnt_dofadr"][j]] = 1
+    jid = m["dof_jntid"]
+    k["k_dof_i"] = np.stack([m["dof_bodyid"], jid, kind, ddepth, Madr, dpar, dof_qposadr, act_of_dof, lim,
+                             k["k_body_root"][m["dof_bodyid"]]], axis=1).astype(np.int32)       # 10 ints
+    hinge = (kind == 6)
+    k["k_dof_f"] = np.stack([
+        m["dof_armature"], m["dof_damping"], np.where(hinge, m["jnt_stiffness"][jid], 0.0),
+        np.where(hinge, m["qpos_spring"][dof_qposadr], 0.0),
+        m["jnt_range"][jid, 0], m["jnt_range"][jid, 1], m["jnt_solref"][jid, 0], m["jnt_solref"][jid, 1],
+        m["jnt_solimp"][jid, 0], m["jnt_solimp"][jid, 1], m["jnt_solimp"][jid, 2], m["jnt_solimp"][jid, 3],
+        m["jnt_solimp"][jid, 4], m["dof_invweight0"], np.zeros(nv), np.zeros(nv)], axis=1)         # 16 floats
+    nu = int(m["nu"])
+    k["k_act_f"] = np.stack([m["actuator_gainprm0"], m["actuator_biasprm"][:, 0], m["actuator_biasprm"][:, 1],
+                             m["actuator_biasprm"][:, 2], m["actuator_dynprm0"], m["actuator_ctrlrange"][:, 0],
+                             m["actuator_ctrlrange"][:, 1], np.zeros(nu)], axis=1)                   # 8 floats
+
+    # ---- sparse M: element -> (row dof i, col dof j), and row address of the column's own row
+    anc_adr, anc = m["dof_ancadr"], m["dof_anc"]       # chain root..self
+    M_ij = np.zeros(nM, np.int32)
+    M_rowadr = np.zeros(nM, np.int32)                  # for element (k, a_p): Madr[a_p]
+    for i in range(nv):
+        chain = anc[anc_adr[i]:anc_adr[i + 1]][::-1]   # self, parent, ..., root
+        for p, j in enumerate(chain):
+            M_ij[Madr[i] + p] = i | (int(j) << 16)
+            M_rowadr[Madr[i] + p] = Madr[j]
+    k["k_M_ij"] = M_ij
+    k["k_M_rowadr"] = M_rowadr
+    # triangular pair table for the factorisation: t -> (p, q), 1 <= p <= q, ordered by q then p
+    dmax = int(ddepth.max())
+    tri = [(p | (q << 8)) for q in range(1, dmax + 1) for p in range(1, q + 1)]
+    k["k_tri"] = np.asarray(tri if tri else [0], np.int32)
+
+    W = NVS * LANES
+
+    def lane_table(rows):
+        """rows[d] = list of packed ints for dof d -> [T][W] table padded with -1."""
+        T = max(1, max((len(r) for r in rows), default=1))
+        out = np.full((T, W), -1, np.int32)
+        for d, r in enumerate(rows):
+            for t, v in enumerate(r):
+                out[t, d] = v
+        return out
+
+    # ---- M*x: full symmetric row of dof i: (col, address)
+    rows = [[] for _ in range(nv)]
+    for i in range(nv):
+        chain = anc[anc_adr[i]:anc_adr[i + 1]][::-1]
+        for p, j in enumerate(chain):
+            rows[i].append(int(j) | ((Madr[i] + p) << 8))
+            if p > 0:
+                rows[int(j)].append(i | ((Madr[i] + p) << 8))
+    k["k_mulm"] = lane_table(rows)
+
+    # ---- L^-1 forward substitution by dof depth level: at step l every dof deeper than l
+    #      subtracts L[i, anc_l(i)] * x[anc_l(i)]   (chain[l] = ancestor at depth l)
+    ndl = dmax + 1
+    fwd = np.full((max(1, dmax), W), -1, np.int32)
+    for i in range(nv):
+        chain = anc[anc_adr[i]:anc_adr[i + 1]]         # root..self; chain[l] has depth l
+        for l in range(ddepth[i]):
+            j = int(chain[l])
+            fwd[l, i] = j | ((Madr[i] + (ddepth[i] - l)) << 8)
+    k["k_solve_fwd"] = fwd
+    # ---- L^-T backward substitution: levels deep -> shallow; dof j gathers its descendants at depth l
+    desc_by_level = [[[] for _ in range(nv)] for _ in range(ndl)]
+    for i in range(nv):
+        chain = anc[anc_adr[i]:anc_adr[i + 1]]
+        for l in range(ddepth[i]):
+            j = int(chain[l])
+            desc_by_level[ddepth[i]][j].append(i | ((Madr[i] + (ddepth[i] - l)) << 8))
+    bwd_rows, bwd_adr = [], [0]
+    for l in range(dmax, 0, -1):
+        T = max(len(r) for r in desc_by_level[l])
+        for t in range(T):
+            row = np.full(W, -1, np.int32)
+            for j in range(nv):
+                if t < len(desc_by_level[l][j]):
+                    row[j] = desc_by_level[l][j][t]
+            bwd_rows.append(row)
+        bwd_adr.append(len(bwd_rows))
+    k["k_solve_bwd"] = np.stack(bwd_rows) if bwd_rows else np.full((1, W), -1, np.int32)
+    k["k_solve_bwd_adr"] = np.asarray(bwd_adr, np.int32)     # entry i: first row of level dmax-i
+
+    # ---- contacts
+    WC = NCS * LANES
+    g2 = m["con_geom2"]
+    g1 = m["con_geom1"]
+    body = m["con_body2"]
+    lastdof = m["con_lastdof"]
+    nanc = np.asarray([(ddepth[d] + 1) if d >= 0 else 0 for d in lastdof], np.int32).reshape(ncon)
+    k["k_con_i"] = np.stack([m["con_kind"], body, k["k_body_root"][body] if ncon else np.zeros(0, np.int32),
+                             lastdof, nanc, m["con_jadr"][:-1], g1, g2], axis=1).astype(np.int32).reshape(ncon, 8)
+    # plane (geom1) is on the world body: world pose = local pose
+    from .mjcf import quat_to_mat
+    pn = np.array([quat_to_mat(m["geom_quat"][g])[:, 2] for g in g1]).reshape(ncon, 3)
+    mu = m["con_friction"][:, 0] if ncon else np.zeros(0)
+    invw = (m["con_invweight"] + mu * mu * m["con_invweight"]) * 2 * mu * mu / float(m["opt_impratio"])
+    k["k_con_f"] = np.concatenate([
+        m["geom_pos"][g2].reshape(ncon, 3), m["geom_quat"][g2].reshape(ncon, 4), m["geom_size"][g2].reshape(ncon, 3),
+        pn, m["geom_pos"][g1].reshape(ncon, 3), mu[:, None], invw[:, None],
+        m["con_solref"].reshape(ncon, 2), m["con_solimp"].reshape(ncon, 5), np.zeros((ncon, 1))], axis=1)  # 26 floats
+    # chain of ancestor dofs per contact, [p][lane], leaf first so shallow chains end early
+    maxc = int(nanc.max()) if ncon else 1
+    chain_tab = np.full((max(1, maxc), WC), -1, np.int32)
+    rows = [[] for _ in range(nv)]                     # J^T f gather lists per dof
+    for c in range(ncon):
+        d = int(lastdof[c])
+        if d < 0:
+            continue
+        chain = anc[anc_adr[d]:anc_adr[d + 1]][::-1]   # leaf..root
+        for p, dd in enumerate(chain):
+            chain_tab[p, c] = int(dd)
+            rows[int(dd)].append(c | ((m["con_jadr"][c] + 3 * p) << 8))
+    k["k_con_chain"] = chain_tab
+    k["k_jtf"] = lane_table(rows)
+    return k

@@ -542,6 +542,8 @@ def compile_mjcf(xml_path: str, *, iterations: int = 6, ls_iterations: int = 6,
     _set_const(m)
     _collision_tables(m)
     _engine_tables(m)
+    from .ktables import build_kernel_tables
+    m.update(build_kernel_tables(m))
     return m
 
 
@@ -796,7 +798,7 @@ def save_blob(m: Dict[str, np.ndarray], path: str):
         v = v.astype(np.int32) if np.issubdtype(v.dtype, np.integer) else v.astype(np.float32)
         if v.ndim > 4:
             raise ValueError(k)
-        entries.append((k, np.ascontiguousarray(v)))
+        entries.append((k, np.require(v, requirements='C')))
     header = 8 + len(entries) * (32 + 4 + 4 + 16 + 8 + 8)
     off = (header + 15) // 16 * 16
     recs, data = [], []

@@ -1,0 +1,122 @@
+/* rodent_rr.h -- C ABI of librodent_hip.so: the MI355X-native replacement for the one hot path of
+ * talmolab/Brax-Rodent-Run, the batched `Rodent.step()` / `pipeline_step` physics
+ * [REF Rodent_Env_Brax.py:87 pipeline_init, :101 pipeline_step, :98-136 step, :138-158 _get_obs].
+ *
+ * In the reference that path is `PipelineEnv.pipeline_init/pipeline_step` dispatching to the backend
+ * module pair `brax.mjx.pipeline.init(sys,q,qd,act,ctrl)` / `step(sys,state,act)` (selected by
+ * `backend='mjx'` [REF Rodent_Env_Brax.py:58]).  This header is what a ctypes/cffi binding of a fifth
+ * backend would bind (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *  - Every `float*` / `int32_t*` data argument is a CALLER-OWNED DEVICE pointer (e.g. torch tensor
+ *    storage on the batch's HIP device), env-major row-major `[num_envs][width]`, valid until the
+ *    work enqueued on the batch's stream has completed.  Nothing is copied to the host.
+ *  - All work is enqueued asynchronously on the `hipStream_t` given at rr_batch_create.
+ *  - Return value: 0 on success, negative rr_status on error; message via rr_last_error()
+ *    (thread-local).  No exceptions cross the ABI; no abort().
+ *  - rr_model is immutable and may be shared by batches on several devices; an rr_batch is not
+ *    thread-safe.  The library keeps no per-env state: all state lives in the caller's buffers.
+ */
+#ifndef RODENT_RR_H
+#define RODENT_RR_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rr_model rr_model;
+typedef struct rr_batch rr_batch;
+
+enum rr_status { RR_OK = 0, RR_EINVAL = -1, RR_EIO = -2, RR_EHIP = -3, RR_EUNSUPPORTED = -4 };
+
+/* model dimensions (what `sys.nq/nv/nu`, obs size etc. are in the reference) */
+typedef struct rr_dims {
+  int32_t nq, nv, nu, na, nbody, njnt, ngeom, nM, ncon, nlimit, nefc, obs_dim;
+  int32_t iterations, ls_iterations; /* opt.iterations / opt.ls_iterations [REF Rodent_Env_Brax.py:46-47] */
+  int32_t lds_bytes;                 /* dynamic LDS one environment (= one wavefront) uses */
+  int32_t dbg_floats;                /* floats per env of the debug dump (rr_debug_layout) */
+  float timestep;
+} rr_dims;
+
+/* physics state of the batch: what survives between `pipeline_step` calls (mjx.Data qpos, qvel, act,
+ * qacc_warmstart).  All in/out, [N][nq], [N][nv], [N][na], [N][nv]. */
+typedef struct rr_state {
+  float* qpos;
+  float* qvel;
+  float* act;
+  float* qacc_warmstart;
+} rr_state;
+
+/* optional per-step outputs read by the reference env (`data.cinert, data.cvel, data.qfrc_actuator,
+ * data.xmat, data.xpos` [REF Rodent_Env_Brax.py:151-155,161]); any pointer may be NULL.
+ * Values are those of the LAST forward pass (before the last integration), as in mjx.step. */
+typedef struct rr_outputs {
+  float* cinert;        /* [N][nbody*10] */
+  float* cvel;          /* [N][nbody*6]  */
+  float* qfrc_actuator; /* [N][nv]       */
+  float* xpos;          /* [N][nbody*3]  */
+  float* xmat;          /* [N][nbody*9]  */
+  float* subtree_com;   /* [N][3]  (root 0) */
+  float* debug;         /* [N][dims.dbg_floats], see rr_debug_layout; NULL in production */
+} rr_outputs;
+
+/* reference-env epilogue fused into the step kernel [REF Rodent_Env_Brax.py:98-136]; all NULL = physics only */
+typedef struct rr_env_io {
+  const float* track_pos; /* [T][3] device */
+  int32_t track_len;      /* T */
+  int32_t* cur_frame;     /* [N] in/out: info['cur_frame'] */
+  float* obs;             /* [N][obs_dim] out */
+  float* reward;          /* [N] out */
+  float* done;            /* [N] out */
+  float* metrics;         /* [N][3] out: pos_reward, reward_quadctrl, reward_alive */
+  float healthy_reward, ctrl_cost_weight, healthy_z_min, healthy_z_max;
+  int32_t terminate_when_unhealthy;
+} rr_env_io;
+
+/* -- model ------------------------------------------------------------------------------------- */
+/* Load a compiled model blob ('RRM1', written by rodent_amd.mjcf.save_blob).  Replaces
+ * mujoco.MjModel.from_xml_path + brax.io.mjcf.load_model -> mjx.put_model [REF Rodent_Env_Brax.py:41,51]. */
+int rr_model_load(const char* blob_path, rr_model** out);
+int rr_model_dims(const rr_model* m, rr_dims* out);
+/* opt.iterations / opt.ls_iterations override [REF Rodent_Env_Brax.py:46-47] (before rr_batch_create) */
+int rr_model_set_solver(rr_model* m, int32_t iterations, int32_t ls_iterations);
+void rr_model_destroy(rr_model* m);
+
+/* -- batch ------------------------------------------------------------------------------------- */
+/* Upload the model tables to `hip_device` and bind `hip_stream` (a hipStream_t, may be NULL = default). */
+int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t hip_device, void* hip_stream, rr_batch** out);
+void rr_batch_destroy(rr_batch* b);
+
+/* brax.mjx.pipeline.init(sys, q, qd) = make_data + mjx.forward [REF Rodent_Env_Brax.py:87].
+ * Reads st->qpos/qvel/act (act normally zero), writes st->qacc_warmstart and the outputs. */
+int rr_pipeline_init(rr_batch* b, const rr_state* st, const rr_outputs* out);
+
+/* brax.mjx.pipeline.step(sys, state, act) x n_frames [REF Rodent_Env_Brax.py:101, :53-57]:
+ * ctrl [N][nu] is held over the n_frames substeps; st is updated in place. */
+int rr_pipeline_step(rr_batch* b, const rr_state* st, const float* ctrl, int32_t n_frames, const rr_outputs* out);
+
+/* Rodent.step fused: pipeline_step + reward/done/obs/metrics + cur_frame increment
+ * [REF Rodent_Env_Brax.py:98-136]. `action` plays the role of ctrl. */
+int rr_env_step(rr_batch* b, const rr_state* st, const float* action, int32_t n_frames, const rr_env_io* env,
+                const rr_outputs* out);
+
+/* obs of Rodent.reset: after rr_pipeline_init, obs = _get_obs(data, 0, cur_frame) [REF :89];
+ * implemented as rr_pipeline_init + obs epilogue in one launch. Only env->obs/track_pos/cur_frame are used. */
+int rr_env_reset(rr_batch* b, const rr_state* st, const rr_env_io* env, const rr_outputs* out);
+
+/* Debug dump layout: names[i] begins at float offsets[i] of each env's debug row; returns the field count. */
+int rr_debug_layout(const rr_batch* b, const char*** names, const int32_t** offsets, const int32_t** sizes);
+
+/* ms of the most recent step-kernel launches on this batch measured with hipEvents on its stream
+ * (enable with rr_batch_set_timing(b,1); each launch is then bracketed by events) */
+int rr_batch_set_timing(rr_batch* b, int32_t enable);
+int rr_batch_kernel_time(rr_batch* b, double* total_ms, int64_t* launches);
+
+const char* rr_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,113 @@
+"""GPU parity: the HIP step kernel (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances are float32 round-off scaled: the oracle runs in float64; per-stage fields of ONE forward
+pass from identical inputs must agree to ~1e-4 of the field's scale (1e-5 for the pure-kinematics
+fields); integer indices are bit-exact (tests/test_mjcf_compile.py pins the contact id list).
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _to_dev(st, dev):
+    return {k: torch.tensor(v, dtype=torch.float32, device=dev).contiguous() for k, v in st.items()}
+
+
+def _rel(a, b):
+    scale = max(np.abs(b).max(), 1e-30)
+    return np.abs(a - b).max() / scale
+
+
+# field -> (oracle name, tolerance relative to the field's max magnitude)
+STAGES = [("xpos", "xpos", 2e-6), ("xquat", "xquat", 2e-6), ("xmat", "xmat", 2e-6), ("cinert", "cinert", 2e-5),
+          ("crb", "crb", 2e-5), ("cdof", "cdof", 2e-5), ("cvel", "cvel", 5e-5), ("qM", "qM", 5e-5), ("qLD", "qLD", 2e-3),
+          ("qfrc_bias", "qfrc_bias", 2e-4), ("qfrc_passive", "qfrc_passive", 1e-5), ("qfrc_actuator", "qfrc_actuator", 1e-5),
+          ("qfrc_smooth", "qfrc_smooth", 2e-4), ("qacc_smooth", "qacc_smooth", 2e-3), ("con_dist", "con_dist", 1e-4),
+          ("con_pos", "con_pos", 1e-5), ("con_frame", "con_frame", 1e-5)]
+
+
+@pytest.mark.parametrize("model_name", ["rodent_optimized", "rodent_new"])
+def test_forward_stages_match_oracle(model_name, oracle_built):
+    from rodent_amd import assets, hip
+    ref = oracle_built
+    N = 48
+    st, M, m = util.settled_states(ref, model_name, N, seed=1, iterations=(8, 8))
+    dev = torch.device("cuda:0")
+    model = hip.Model(assets.asset_path(model_name), iterations=8, ls_iterations=8)
+    batch = hip.Batch(model, N, dev)
+    rng = np.random.default_rng(5)
+    ctrl = rng.uniform(-1, 1, (N, M.nu))
+    ds = _to_dev(st, dev)
+    dbg = torch.zeros(N, batch.dims.dbg_floats, device=dev)
+    batch.pipeline_step(ds, torch.tensor(ctrl, dtype=torch.float32, device=dev), 1, out=dict(debug=dbg))
+    torch.cuda.synchronize()
+    lay = batch.debug_layout()
+    dbg = dbg.cpu().numpy().astype(np.float64)
+    worst = {}
+    nact = 0
+    for e in range(N):
+        d = util.oracle_forward(ref, M, st, e, ctrl[e])
+        for name, oname, tol in STAGES:
+            o, n = lay[name]
+            got, want = dbg[e, o:o + n], d.get(oname)
+            worst[name] = max(worst.get(name, 0), _rel(got, want))
+        active = d.get("con_dist") < 0
+        nact += active.sum()
+        # constraint rows of active contacts: D and aref (4 pyramid rows each)
+        o, n = lay["con_D"]
+        D = d.get("efc_D")[M.nlimit:].reshape(-1, 4)[:, 0]
+        aref = d.get("efc_aref")[M.nlimit:].reshape(-1, 4)
+        if active.any():
+            worst["con_D"] = max(worst.get("con_D", 0), _rel(dbg[e, o:o + n][active], D[active]))
+            o, n = lay["con_aref"]
+            worst["con_aref"] = max(worst.get("con_aref", 0), _rel(dbg[e, o:o + n].reshape(-1, 4)[active], aref[active]))
+    print("worst relative error per stage:", {k: f"{v:.2e}" for k, v in worst.items()}, "active contacts/env", nact / N)
+    assert nact > N            # the scenario exercises contacts
+    tol = {n: t for n, _, t in STAGES}
+    tol.update(con_D=1e-3, con_aref=2e-3)
+    bad = {k: v for k, v in worst.items() if not v <= tol[k]}
+    assert not bad, bad
+
+
+def test_solver_and_substep_match_oracle(oracle_built):
+    """qacc after the CG solve and qpos/qvel after one substep, same inputs (float32 vs float64 oracle)."""
+    from rodent_amd import assets, hip
+    ref = oracle_built
+    N = 48
+    st, M, m = util.settled_states(ref, "rodent_optimized", N, seed=2, iterations=(8, 8))
+    dev = torch.device("cuda:0")
+    batch = hip.Batch(hip.Model(assets.asset_path("rodent_optimized"), 8, 8), N, dev)
+    ctrl = np.random.default_rng(6).uniform(-1, 1, (N, M.nu))
+    ds = _to_dev(st, dev)
+    dbg = torch.zeros(N, batch.dims.dbg_floats, device=dev)
+    batch.pipeline_step(ds, torch.tensor(ctrl, dtype=torch.float32, device=dev), 1, out=dict(debug=dbg))
+    torch.cuda.synchronize()
+    lay = batch.debug_layout()
+    dbg = dbg.cpu().numpy().astype(np.float64)
+    err_qacc, err_qvel, err_qpos, err_f = [], [], [], []
+    for e in range(N):
+        d = util.oracle_forward(ref, M, st, e, ctrl[e])
+        o, n = lay["qacc"]
+        qacc = d.get("qacc")
+        err_qacc.append(np.abs(dbg[e, o:o + n] - qacc).max() / max(np.abs(qacc).max(), 1.0))
+        o, n = lay["qfrc_constraint"]
+        fc = d.get("qfrc_constraint")
+        err_f.append(np.abs(dbg[e, o:o + n] - fc).max() / max(np.abs(fc).max(), 1e-3))
+        d2 = ref.RefData(M)
+        for k in ("qpos", "qvel", "act", "qacc_warmstart"):
+            d2.set(k, st[k][e])
+        d2.step(ctrl[e], 1)
+        dv = np.abs(d2.get("qvel") - st["qvel"][e]).max()           # scale: the substep's velocity change
+        err_qvel.append(np.abs(ds["qvel"][e].cpu().numpy() - d2.get("qvel")).max() / max(dv, 1e-3))
+        err_qpos.append(np.abs(ds["qpos"][e].cpu().numpy() - d2.get("qpos")).max())
+    print("qacc rel err: median %.2e max %.2e | qfrc_constraint rel: median %.2e max %.2e | qvel err / max|dqvel| max %.2e | qpos abs max %.2e"
+          % (np.median(err_qacc), np.max(err_qacc), np.median(err_f), np.max(err_f), np.max(err_qvel), np.max(err_qpos)))
+    # a truncated (8-iteration) CG run in float32 vs float64: branchy line search -> allow a few outliers
+    assert np.median(err_qacc) < 2e-3
+    assert np.max(err_qacc) < 1e-3 and np.max(err_f) < 5e-3
+    assert np.max(err_qpos) < 5e-5
+    assert np.median(err_qvel) < 1e-4 and np.max(err_qvel) < 2e-3
