@@ -1,0 +1,123 @@
+"""`State` / `PipelineState` / `PipelineEnv`: the torch-tensor mirror of `brax.envs.base`
+(the reference imports `PipelineEnv, State` from there [REF Rodent_Env_Brax.py:4]).
+
+Batched by construction: every leaf has a leading env axis [N, ...] instead of being vmapped.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Any, Dict, Optional
+
+import torch
+
+from .. import assets, hip
+
+
+@dataclasses.dataclass
+class PipelineState:
+    """What the reference env reads from `mjx.Data` [REF Rodent_Env_Brax.py:110,116,151-155,161]."""
+    qpos: torch.Tensor            # [N, nq]
+    qvel: torch.Tensor            # [N, nv]
+    act: torch.Tensor             # [N, na]
+    qacc_warmstart: torch.Tensor  # [N, nv]
+    cinert: torch.Tensor          # [N, nbody, 10]
+    cvel: torch.Tensor            # [N, nbody, 6]
+    qfrc_actuator: torch.Tensor   # [N, nv]
+    xpos: torch.Tensor            # [N, nbody, 3]
+    xmat: torch.Tensor            # [N, nbody, 9]
+
+    @property
+    def q(self):
+        return self.qpos
+
+    @property
+    def qd(self):
+        return self.qvel
+
+    def replace(self, **kw):
+        return dataclasses.replace(self, **kw)
+
+    def tree(self):
+        return {f.name: getattr(self, f.name) for f in dataclasses.fields(self)}
+
+
+@dataclasses.dataclass
+class State:
+    """Environment state for training and inference (brax.envs.base.State)."""
+    pipeline_state: Optional[PipelineState]
+    obs: torch.Tensor
+    reward: torch.Tensor
+    done: torch.Tensor
+    metrics: Dict[str, torch.Tensor] = dataclasses.field(default_factory=dict)
+    info: Dict[str, Any] = dataclasses.field(default_factory=dict)
+
+    def replace(self, **kw):
+        return dataclasses.replace(self, **kw)
+
+
+class System:
+    """The few `sys.*` attributes the reference env touches [REF Rodent_Env_Brax.py:82-89]."""
+
+    def __init__(self, blob_path: str, iterations: int, ls_iterations: int):
+        from .. import mjcf
+        self.blob_path = blob_path
+        self.tables = mjcf.load_blob(blob_path)
+        self.model = hip.Model(blob_path, iterations=iterations, ls_iterations=ls_iterations)
+        d = self.model.dims
+        self.nq, self.nv, self.nu, self.na, self.nbody = d.nq, d.nv, d.nu, d.na, d.nbody
+        self.obs_dim = d.obs_dim
+        self.dt = float(d.timestep)
+        self.qpos0 = self.tables["qpos0"]
+
+
+class PipelineEnv:
+    """API for driving the HIP physics backend (`brax.envs.base.PipelineEnv` with backend='mjx'
+    replaced by the fused HIP kernel): `pipeline_init` / `pipeline_step` [REF Rodent_Env_Brax.py:87,101]."""
+
+    def __init__(self, sys: System, num_envs: int, n_frames: int = 1, backend: str = "hip", device=None, debug=False):
+        if backend not in ("hip", "mjx"):
+            raise ValueError(f"backend {backend!r} not available: this build provides the HIP backend only")
+        self.sys = sys
+        self._n_frames = n_frames
+        self._debug = debug
+        self.num_envs = int(num_envs)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._batch = hip.Batch(sys.model, self.num_envs, self.device)
+
+    # -- brax surface
+    @property
+    def dt(self) -> float:
+        return self.sys.dt * self._n_frames
+
+    @property
+    def observation_size(self) -> int:
+        return self.sys.obs_dim
+
+    @property
+    def action_size(self) -> int:
+        return self.sys.nu
+
+    @property
+    def backend(self) -> str:
+        return "hip"
+
+    def _alloc_outputs(self):
+        N, s, dev = self.num_envs, self.sys, self.device
+        return dict(cinert=torch.empty(N, s.nbody, 10, device=dev), cvel=torch.empty(N, s.nbody, 6, device=dev),
+                    qfrc_actuator=torch.empty(N, s.nv, device=dev), xpos=torch.empty(N, s.nbody, 3, device=dev),
+                    xmat=torch.empty(N, s.nbody, 9, device=dev))
+
+    def pipeline_init(self, q: torch.Tensor, qd: torch.Tensor) -> PipelineState:
+        N, s, dev = self.num_envs, self.sys, self.device
+        st = dict(qpos=q.to(dev, torch.float32).contiguous().clone(), qvel=qd.to(dev, torch.float32).contiguous().clone(),
+                  act=torch.zeros(N, s.na, device=dev), qacc_warmstart=torch.zeros(N, s.nv, device=dev))
+        out = self._alloc_outputs()
+        self._batch.pipeline_init(st, out)
+        return PipelineState(**st, **out)
+
+    def pipeline_step(self, pipeline_state: PipelineState, action: torch.Tensor) -> PipelineState:
+        st = dict(qpos=pipeline_state.qpos.clone(), qvel=pipeline_state.qvel.clone(), act=pipeline_state.act.clone(),
+                  qacc_warmstart=pipeline_state.qacc_warmstart.clone())
+        out = self._alloc_outputs()
+        self._batch.pipeline_step(st, action.to(self.device, torch.float32).contiguous(), self._n_frames, out)
+        return PipelineState(**st, **out)

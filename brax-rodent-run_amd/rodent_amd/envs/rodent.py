@@ -1,0 +1,107 @@
+"""`Rodent`: the reference task env [REF Rodent_Env_Brax.py:19-162] on the HIP backend.
+
+Same constructor arguments, `reset(rng)` / `step(state, action)` surface, reward / done / obs
+arithmetic and `info['cur_frame']` bookkeeping as the reference; tensors are torch (leading env
+axis N) instead of vmapped jax arrays.  `step` runs ONE fused kernel launch: n_frames physics
+substeps + reward / done / observation epilogue (C ABI `rr_env_step`).
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import assets, jax_random
+from .base import PipelineEnv, PipelineState, State, System
+
+_XML_PATH = "./models/rodent_new.xml"   # [REF Rodent_Env_Brax.py:16]
+
+
+class Rodent(PipelineEnv):
+
+    def __init__(
+        self,
+        track_pos,
+        forward_reward_weight=10,
+        ctrl_cost_weight=0.1,
+        healthy_reward=1.0,
+        terminate_when_unhealthy=True,
+        healthy_z_range=(0.03, 0.5),
+        reset_noise_scale=1e-2,
+        solver="cg",
+        iterations: int = 6,
+        ls_iterations: int = 6,
+        vision=False,
+        num_envs: int = 1,
+        xml_path: str = _XML_PATH,
+        device=None,
+        **kwargs,
+    ):
+        if solver.lower() != "cg":
+            raise NotImplementedError("only the CG solver is implemented (the reference launcher uses cg)")
+        if vision:
+            raise NotImplementedError("vision observations are not part of the reference obs either")
+        sys = System(assets.resolve_model(xml_path), iterations, ls_iterations)
+        physics_steps_per_control_step = 10   # [REF Rodent_Env_Brax.py:53-57]
+        kwargs["n_frames"] = kwargs.get("n_frames", physics_steps_per_control_step)
+        kwargs["backend"] = "hip"
+        super().__init__(sys, num_envs=num_envs, device=device, **kwargs)
+        self._track_pos = torch.as_tensor(np.asarray(track_pos), dtype=torch.float32).to(self.device).contiguous()
+        self._forward_reward_weight = forward_reward_weight
+        self._ctrl_cost_weight = ctrl_cost_weight
+        self._healthy_reward = healthy_reward
+        self._terminate_when_unhealthy = terminate_when_unhealthy
+        self._healthy_z_range = healthy_z_range
+        self._reset_noise_scale = reset_noise_scale
+        self._vision = vision
+
+    def _env_io(self, cur_frame, obs, reward=None, done=None, metrics=None):
+        return dict(track_pos=self._track_pos, cur_frame=cur_frame, obs=obs, reward=reward, done=done, metrics=metrics,
+                    healthy_reward=self._healthy_reward, ctrl_cost_weight=self._ctrl_cost_weight,
+                    healthy_z_range=self._healthy_z_range, terminate_when_unhealthy=self._terminate_when_unhealthy)
+
+    def reset(self, rng) -> State:
+        """Resets the environment to an initial state.  `rng`: uint32 keys [N, 2] (one jax-style
+        PRNG key per env, as `jax.vmap(env.reset)(split(key, N))` passes) or an int seed."""
+        N, dev, s = self.num_envs, self.device, self.sys
+        if isinstance(rng, (int, np.integer)):
+            rng = jax_random.split(jax_random.PRNGKey(int(rng)), N)
+        keys = np.asarray(rng, dtype=np.uint32).reshape(N, 2)
+        ks = jax_random.split(keys, 4)                       # rng, rng1, rng2, rng_pos
+        start_frame = jax_random.randint(ks[:, 0], 0, 100)   # [N] int32
+        low, hi = -self._reset_noise_scale, self._reset_noise_scale
+        track = self._track_pos.cpu().numpy()
+        qpos = np.tile(np.asarray(s.qpos0, dtype=np.float32), (N, 1))
+        qpos[:, :3] = track[np.clip(start_frame, 0, len(track) - 1)]
+        qpos = qpos + jax_random.uniform(ks[:, 1], s.nq, low, hi)
+        qvel = jax_random.uniform(ks[:, 2], s.nv, low, hi)
+
+        st = dict(qpos=torch.from_numpy(qpos).to(dev), qvel=torch.from_numpy(qvel).to(dev),
+                  act=torch.zeros(N, s.na, device=dev), qacc_warmstart=torch.zeros(N, s.nv, device=dev))
+        out = self._alloc_outputs()
+        cur_frame = torch.from_numpy(start_frame.astype(np.int32)).to(dev)
+        obs = torch.empty(N, s.obs_dim, device=dev)
+        self._batch.env_reset(st, self._env_io(cur_frame, obs), out)
+        zero = torch.zeros(N, device=dev)
+        metrics = {"pos_reward": zero, "reward_quadctrl": zero.clone(), "reward_alive": zero.clone()}
+        return State(PipelineState(**st, **out), obs, zero.clone(), zero.clone(), metrics, {"cur_frame": cur_frame})
+
+    def step(self, state: State, action: torch.Tensor) -> State:
+        """Runs one timestep of the environment's dynamics."""
+        N, dev, s = self.num_envs, self.device, self.sys
+        ps = state.pipeline_state
+        st = dict(qpos=ps.qpos.clone(), qvel=ps.qvel.clone(), act=ps.act.clone(), qacc_warmstart=ps.qacc_warmstart.clone())
+        out = self._alloc_outputs()
+        cur_frame = state.info["cur_frame"].clone()
+        obs = torch.empty(N, s.obs_dim, device=dev)
+        reward, done = torch.empty(N, device=dev), torch.empty(N, device=dev)
+        metrics = torch.empty(N, 3, device=dev)
+        action = action.to(dev, torch.float32).contiguous()
+        self._batch.env_step(st, action, self._n_frames, self._env_io(cur_frame, obs, reward, done, metrics), out)
+        info = dict(state.info)
+        info["cur_frame"] = cur_frame
+        m = dict(state.metrics)
+        m.update(pos_reward=metrics[:, 0], reward_quadctrl=metrics[:, 1], reward_alive=metrics[:, 2])
+        return state.replace(pipeline_state=PipelineState(**st, **out), obs=obs, reward=reward, done=done, metrics=m, info=info)

@@ -1,0 +1,67 @@
+"""GPU: env-level behaviour of the HIP path against the oracle (reset / step / obs / reward / cur_frame)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk_env(N, model="rodent_optimized"):
+    from rodent_amd import envs
+    return envs.get_environment("rodent", track_pos=util.synthetic_track(), num_envs=N, xml_path=f"{model}.xml",
+                                iterations=8, ls_iterations=8, device="cuda:0")
+
+
+def test_n_frames_fused_equals_repeated_launches():
+    """10 substeps inside one launch == 10 launches of one substep, bit for bit (no state is lost between frames)."""
+    N = 32
+    env = _mk_env(N)
+    state = env.reset(7)
+    ctrl = torch.rand(N, env.action_size, device="cuda:0") * 2 - 1
+    ps = state.pipeline_state
+    a = dict(qpos=ps.qpos.clone(), qvel=ps.qvel.clone(), act=ps.act.clone(), qacc_warmstart=ps.qacc_warmstart.clone())
+    b = {k: v.clone() for k, v in a.items()}
+    env._batch.pipeline_step(a, ctrl, 10)
+    for _ in range(10):
+        env._batch.pipeline_step(b, ctrl, 1)
+    torch.cuda.synchronize()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_env_step_matches_oracle(oracle_built):
+    from rodent_amd import assets
+    ref = oracle_built
+    N = 16
+    env = _mk_env(N)
+    track = util.synthetic_track()
+    state = env.reset(0)
+    action = torch.rand(N, env.action_size, device="cuda:0") * 2 - 1
+    nstate = env.step(state, action)
+    torch.cuda.synchronize()
+    M64 = ref.RefModel(assets.asset_path("rodent_optimized"), "f64"); M64.set_iterations(8, 8)
+    M32 = ref.RefModel(assets.asset_path("rodent_optimized"), "f32"); M32.set_iterations(8, 8)
+    errs, gaps = [], []
+    for e in range(N):
+        res = {}
+        for tag, M in (("f64", M64), ("f32", M32)):
+            d = ref.RefData(M)
+            d.init(state.pipeline_state.qpos[e].cpu().numpy(), state.pipeline_state.qvel[e].cpu().numpy())
+            res[tag] = d.env_step(action[e].cpu().numpy().astype(np.float64), track, int(state.info["cur_frame"][e]), n_frames=10) + (d.get("qpos"),)
+        obs, rew, done, cf, met, qpos = res["f64"]
+        got_q = nstate.pipeline_state.qpos[e].cpu().numpy()
+        errs.append(np.abs(got_q - qpos).max())
+        gaps.append(np.abs(res["f32"][5] - qpos).max())
+        assert int(nstate.info["cur_frame"][e]) == cf            # integer bookkeeping is bit-exact
+        assert float(nstate.done[e]) == done
+        assert abs(float(nstate.reward[e]) - rew) < 1e-3 + 20 * errs[-1]
+        # obs layout: first nq entries are qpos, last 3 the local tracking vector
+        np.testing.assert_allclose(nstate.obs[e, :env.sys.nq].cpu().numpy(), got_q, rtol=0, atol=0)
+        scale = np.maximum(np.abs(obs), 1e-2)
+        assert np.median(np.abs(nstate.obs[e].cpu().numpy() - obs) / scale) < 1e-4
+    print("max |qpos - oracle f64| per env after 1 env-step:", np.array2string(np.array(errs), precision=2))
+    print("oracle f32 vs f64 gap per env:                 ", np.array2string(np.array(gaps), precision=2))
+    # HIP float32 must sit as close to the float64 truth as the scalar float32 oracle does (x10 margin, floor 2e-5)
+    assert np.all(np.array(errs) <= 10 * np.array(gaps) + 2e-5)
