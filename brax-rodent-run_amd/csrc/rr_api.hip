@@ -103,7 +103,7 @@ extern "C" int rr_model_load(const char* path, rr_model** out) {
   static const char* need[] = {"nq", "nv", "nu", "nbody", "njnt", "ngeom", "nM", "ncon", "nlimit", "nefc", "obs_dim", "k_slots",
                                "k_lvl_adr", "k_lvl_body", "k_child", "k_body_i", "k_body_f", "k_jnt_i", "k_jnt_f", "k_dof_i",
                                "k_dof_f", "k_act_f", "k_M_ij", "k_M_rowadr", "k_tri", "k_mulm", "k_solve_fwd", "k_solve_bwd",
-                               "k_solve_bwd_adr", "k_con_i", "k_con_f", "k_con_chain", "k_jtf", "k_root_mass", "con_jadr",
+                               "k_solve_bwd_adr", "k_solve_bwd_level", "k_con_i", "k_con_f", "k_con_chain", "k_jtf", "k_root_mass", "con_jadr",
                                "dof_depth", "body_depth", "opt_timestep", "opt_gravity", "stat_meaninertia"};
   for (const char* nme : need)
     if (!m->find(nme)) { std::string s = std::string("rr_model_load: blob lacks '") + nme + "'"; delete m; return fail(RR_EIO, s); }
@@ -125,12 +125,14 @@ extern "C" int rr_model_load(const char* path, rr_model** out) {
   { const Entry* dd = m->find("dof_depth"); for (size_t i = 0; i < dd->count; ++i) dmax = std::max(dmax, ((const int32_t*)dd->data)[i]); }
   k.dmax = dmax;
   k.nroot = (int)m->find("k_root_mass")->count;
+  k.ntri = (int)m->find("k_tri")->count;
   k.T_mulm = m->find("k_mulm")->dims[0]; k.T_jtf = m->find("k_jtf")->dims[0]; k.T_chain = m->find("k_con_chain")->dims[0];
   k.obs_dim = d.obs_dim; k.iterations = d.iterations; k.ls_iterations = d.ls_iterations;
   k.dt = d.timestep; k.gx = m->fscalar("opt_gravity", 0); k.gy = m->fscalar("opt_gravity", 1); k.gz = m->fscalar("opt_gravity", 2);
   k.tolerance = m->fscalar("opt_tolerance"); k.ls_tolerance = m->fscalar("opt_ls_tolerance");
   k.meaninertia = m->fscalar("stat_meaninertia");
   if (k.nroot > 2) { delete m; return fail(RR_EUNSUPPORTED, "rr_model_load: more than 2 kinematic trees"); }
+  if (m->find("k_dof_i")->dims[1] != RR_DOFI) { delete m; return fail(RR_EIO, "rr_model_load: k_dof_i width mismatch (stale blob)"); }
   if (d.nv > 256 || d.ncon > 256) { delete m; return fail(RR_EUNSUPPORTED, "rr_model_load: nv/ncon above the 8-bit table index"); }
   if (m->find("k_mulm")->dims[1] != m->NVS * RR_LANES || m->find("k_con_chain")->dims[1] != m->NCS * RR_LANES) {
     delete m; return fail(RR_EIO, "rr_model_load: lane-table width mismatch");
@@ -198,7 +200,7 @@ extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t devi
 #define UP(field, name) if ((rc = upload(b, name, &b->T.field))) { rr_batch_destroy(b); return rc; }
   UP(lvl_adr, "k_lvl_adr") UP(lvl_body, "k_lvl_body") UP(child, "k_child") UP(body_i, "k_body_i") UP(jnt_i, "k_jnt_i")
   UP(dof_i, "k_dof_i") UP(M_ij, "k_M_ij") UP(M_rowadr, "k_M_rowadr") UP(tri, "k_tri") UP(mulm, "k_mulm")
-  UP(solve_fwd, "k_solve_fwd") UP(solve_bwd, "k_solve_bwd") UP(solve_bwd_adr, "k_solve_bwd_adr") UP(con_i, "k_con_i")
+  UP(solve_fwd, "k_solve_fwd") UP(solve_bwd, "k_solve_bwd") UP(solve_bwd_adr, "k_solve_bwd_adr") UP(solve_bwd_level, "k_solve_bwd_level") UP(con_i, "k_con_i")
   UP(con_chain, "k_con_chain") UP(jtf, "k_jtf") UP(body_f, "k_body_f") UP(jnt_f, "k_jnt_f") UP(dof_f, "k_dof_f")
   UP(act_f, "k_act_f") UP(con_f, "k_con_f") UP(root_mass, "k_root_mass")
 #undef UP

@@ -17,13 +17,15 @@
 #include <stdint.h>
 
 #define RR_LANES 64
+#define RR_DOFI 12   // ints per dof in k_dof_i
+#define RR_U 8       // lane tables are consumed in batches of RR_U rows: their loads are issued together
 #define RR_MINVAL 1e-15f
 #define RR_MINIMP 0.0001f
 #define RR_MAXIMP 0.9999f
 
 struct RRDims {
   int nq, nv, nu, nbody, njnt, nM, ncon, nlevel, dmax, nroot;
-  int T_mulm, T_jtf, T_chain, obs_dim, iterations, ls_iterations, nJ;
+  int T_mulm, T_jtf, T_chain, obs_dim, iterations, ls_iterations, nJ, ntri;
   float dt, gx, gy, gz, tolerance, ls_tolerance, meaninertia;
   // LDS offsets (floats)
   int o_qpos, o_qvel, o_act, o_ctrl, o_xpos, o_xquat, o_xmat, o_cinert, o_crb, o_cdof, o_cvel, o_cacc, o_cfrc, o_buf,
@@ -36,7 +38,7 @@ struct RRDims {
 
 struct RRTables {
   const int *lvl_adr, *lvl_body, *child, *body_i, *jnt_i, *dof_i, *M_ij, *M_rowadr, *tri, *mulm, *solve_fwd, *solve_bwd,
-      *solve_bwd_adr, *con_i, *con_chain, *jtf;
+      *solve_bwd_adr, *solve_bwd_level, *con_i, *con_chain, *jtf;
   const float *body_f, *jnt_f, *dof_f, *act_f, *con_f, *root_mass;
 };
 
@@ -165,7 +167,9 @@ struct Wave {
   static constexpr int WC = NCS * RR_LANES;
 
   // per-dof registers (slot s -> dof lane + 64 s)
-  int dofdepth[NVS];
+  int dofdepth[NVS], dofmadr[NVS], doflast[NVS];
+  static constexpr int RR_TRI = 10;   // (p,q) pairs of chains up to depth 35 (630 pairs) live in registers
+  int tri_r[RR_TRI];
   float dinv[NVS];
   float qfrc_smooth[NVS], qfrc_actuator[NVS], qacc_smooth[NVS], act_dot[NVS];
   float qacc[NVS], Ma[NVS], grad[NVS], Mgrad[NVS], search[NVS], mv[NVS], qfrc_con[NVS], warm[NVS];
@@ -315,7 +319,7 @@ struct Wave {
     for (int s = 0; s < NVS; ++s) {
       const int d = lane + RR_LANES * s;
       if (d < D.nv) {
-        const int kind = T.dof_i[10 * d + 2], r = T.dof_i[10 * d + 9];
+        const int kind = T.dof_i[RR_DOFI * d + 2], r = T.dof_i[RR_DOFI * d + 9];
         float* c = s_cdof + 6 * d;
         if (kind < 3) {
           c[0] = c[1] = c[2] = 0;
@@ -409,7 +413,7 @@ struct Wave {
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
       const int d = lane + RR_LANES * s;
-      if (d < D.nv) mul_inert_vec(s_buf + 6 * d, s_crb + 10 * T.dof_i[10 * d], s_cdof + 6 * d);
+      if (d < D.nv) mul_inert_vec(s_buf + 6 * d, s_crb + 10 * T.dof_i[RR_DOFI * d], s_cdof + 6 * d);
     }
     sync();
     for (int e = lane; e < D.nM; e += RR_LANES) {
@@ -421,7 +425,10 @@ struct Wave {
     sync();
   }
 
-  // sparse L'DL in place in s_qLD  [MuJoCo mj_factorM]; damp = dt for the eulerdamp matrix M + dt*diag(damping)
+  // sparse L'DL in place in s_qLD  [MuJoCo mj_factorM]; damp = dt for the eulerdamp matrix M + dt*diag(damping).
+  // No global loads inside the k loop: (p,q) pair indices live in registers (tri_r), the row metadata of
+  // dof k comes from its owner lane by v_readlane, and the row address of each ancestor of k is published
+  // in a small LDS table indexed by depth (ancestor test: j <= k <= last_desc[j], dofs are in DFS preorder).
   __device__ __forceinline__ void factor(float damp) {
     for (int e = lane; e < D.nM; e += RR_LANES) s_qLD[e] = s_qM[e];
     sync();
@@ -429,20 +436,39 @@ struct Wave {
 #pragma unroll
       for (int s = 0; s < NVS; ++s) {
         const int d = lane + RR_LANES * s;
-        if (d < D.nv) s_qLD[T.dof_i[10 * d + 4]] += damp * T.dof_f[16 * d + 1];
+        if (d < D.nv) s_qLD[dofmadr[s]] += damp * T.dof_f[16 * d + 1];
       }
       sync();
     }
+    int* s_anc = reinterpret_cast<int*>(s_x);   // s_x is free during the factorisation
     for (int k = D.nv - 1; k >= 0; --k) {
-      const int dk = T.dof_i[10 * k + 3];
+      int dk = 0, Mkk = 0;
+#pragma unroll
+      for (int s = 0; s < NVS; ++s)
+        if ((k >> 6) == s) { dk = __builtin_amdgcn_readlane(dofdepth[s], k & 63); Mkk = __builtin_amdgcn_readlane(dofmadr[s], k & 63); }
       if (dk > 0) {
-        const int Mkk = T.dof_i[10 * k + 4];
+#pragma unroll
+        for (int s = 0; s < NVS; ++s) {
+          const int d = lane + RR_LANES * s;
+          if (d < k && k <= doflast[s]) s_anc[dofdepth[s]] = dofmadr[s];   // strict ancestors of k
+        }
         const float dkk = s_qLD[Mkk];
+        sync();
         const int npairs = dk * (dk + 1) / 2;
-        for (int t = lane; t < npairs; t += RR_LANES) {
+#pragma unroll
+        for (int i = 0; i < RR_TRI; ++i) {
+          const int t = lane + RR_LANES * i;
+          if (t < npairs) {
+            const int pq = tri_r[i], p = pq & 255, q = pq >> 8;
+            const float tmp = s_qLD[Mkk + p] / dkk;
+            const int adr = s_anc[dk - p] + (q - p);
+            s_qLD[adr] -= s_qLD[Mkk + q] * tmp;
+          }
+        }
+        for (int t = lane + RR_LANES * RR_TRI; t < npairs; t += RR_LANES) {   // deeper trees than the register table
           const int pq = T.tri[t], p = pq & 255, q = pq >> 8;
           const float tmp = s_qLD[Mkk + p] / dkk;
-          const int adr = T.M_rowadr[Mkk + p] + (q - p);
+          const int adr = s_anc[dk - p] + (q - p);
           s_qLD[adr] -= s_qLD[Mkk + q] * tmp;
         }
         sync();
@@ -453,32 +479,49 @@ struct Wave {
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
       const int d = lane + RR_LANES * s;
-      dinv[s] = d < D.nv ? 1.0f / s_qLD[T.dof_i[10 * d + 4]] : 0.0f;
+      dinv[s] = d < D.nv ? 1.0f / s_qLD[dofmadr[s]] : 0.0f;
     }
   }
 
-  // x <- (L' D L)^-1 x, level-synchronous  [MuJoCo mj_solveLD]
+  // x <- (L' D L)^-1 x, level-synchronous  [MuJoCo mj_solveLD].  The table row of the NEXT step is
+  // loaded before the LDS hand-off of the current one, so its global-load latency is hidden.
   __device__ __forceinline__ void ldl_solve(float* x) {
-    for (int li = 0; li < D.dmax; ++li) {
-      const int level = D.dmax - li;
+    const int nrows = T.solve_bwd_adr[D.dmax];
+    int en[NVS], lvn = T.solve_bwd_level[0];
 #pragma unroll
-      for (int s = 0; s < NVS; ++s) {
-        const int d = lane + RR_LANES * s;
-        if (d < D.nv && dofdepth[s] == level) s_x[d] = x[s];
+    for (int s = 0; s < NVS; ++s) en[s] = T.solve_bwd[s * RR_LANES + lane];
+    for (int r = 0; r < nrows; ++r) {
+      int e[NVS];
+      const int lv = lvn;
+#pragma unroll
+      for (int s = 0; s < NVS; ++s) e[s] = en[s];
+      if (r + 1 < nrows) {
+        lvn = T.solve_bwd_level[r + 1];
+#pragma unroll
+        for (int s = 0; s < NVS; ++s) en[s] = T.solve_bwd[(r + 1) * W + s * RR_LANES + lane];
       }
-      sync();
-      const int r0 = T.solve_bwd_adr[li], r1 = T.solve_bwd_adr[li + 1];
-      for (int r = r0; r < r1; ++r) {
+      if (lv >= 0) {   // dofs of depth lv are final: publish them
 #pragma unroll
         for (int s = 0; s < NVS; ++s) {
-          const int e = T.solve_bwd[r * W + s * RR_LANES + lane];
-          if (e >= 0) x[s] -= s_qLD[e >> 8] * s_x[e & 255];
+          const int d = lane + RR_LANES * s;
+          if (d < D.nv && dofdepth[s] == lv) s_x[d] = x[s];
         }
+        sync();
       }
+#pragma unroll
+      for (int s = 0; s < NVS; ++s)
+        if (e[s] >= 0) x[s] -= s_qLD[e[s] >> 8] * s_x[e[s] & 255];
     }
 #pragma unroll
-    for (int s = 0; s < NVS; ++s) x[s] *= dinv[s];
+    for (int s = 0; s < NVS; ++s) { x[s] *= dinv[s]; en[s] = T.solve_fwd[s * RR_LANES + lane]; }
     for (int l = 0; l < D.dmax; ++l) {
+      int e[NVS];
+#pragma unroll
+      for (int s = 0; s < NVS; ++s) e[s] = en[s];
+      if (l + 1 < D.dmax) {
+#pragma unroll
+        for (int s = 0; s < NVS; ++s) en[s] = T.solve_fwd[(l + 1) * W + s * RR_LANES + lane];
+      }
 #pragma unroll
       for (int s = 0; s < NVS; ++s) {
         const int d = lane + RR_LANES * s;
@@ -486,24 +529,27 @@ struct Wave {
       }
       sync();
 #pragma unroll
-      for (int s = 0; s < NVS; ++s) {
-        const int e = T.solve_fwd[l * W + s * RR_LANES + lane];
-        if (e >= 0) x[s] -= s_qLD[e >> 8] * s_x[e & 255];
-      }
+      for (int s = 0; s < NVS; ++s)
+        if (e[s] >= 0) x[s] -= s_qLD[e[s] >> 8] * s_x[e[s] & 255];
     }
     sync();  // s_x may be rewritten by the next call
   }
 
-  // y = M * s_vec   (s_vec must be visible)
+  // y = M * s_vec   (s_vec must be visible); table rows in batches of RR_U
   __device__ __forceinline__ void mul_m(float* y) {
 #pragma unroll
     for (int s = 0; s < NVS; ++s) y[s] = 0.0f;
-    for (int t = 0; t < D.T_mulm; ++t) {
+    for (int t0 = 0; t0 < D.T_mulm; t0 += RR_U) {
+      int e[RR_U][NVS];
 #pragma unroll
-      for (int s = 0; s < NVS; ++s) {
-        const int e = T.mulm[t * W + s * RR_LANES + lane];
-        if (e >= 0) y[s] += s_qM[e >> 8] * s_vec[e & 255];
-      }
+      for (int u = 0; u < RR_U; ++u)
+#pragma unroll
+        for (int s = 0; s < NVS; ++s) e[u][s] = T.mulm[(t0 + u) * W + s * RR_LANES + lane];
+#pragma unroll
+      for (int u = 0; u < RR_U; ++u)
+#pragma unroll
+        for (int s = 0; s < NVS; ++s)
+          if (e[u][s] >= 0) y[s] += s_qM[e[u][s] >> 8] * s_vec[e[u][s] & 255];
     }
   }
 
@@ -525,7 +571,7 @@ struct Wave {
       qfrc_smooth[s] = qfrc_actuator[s] = act_dot[s] = 0.0f;
       bias_out[s] = passive_out[s] = 0.0f;
       if (d < D.nv) {
-        const int* di = T.dof_i + 10 * d;
+        const int* di = T.dof_i + RR_DOFI * d;
         const float* df = T.dof_f + 16 * d;
         const float qv = s_qvel[d];
         float passive = -df[1] * qv;
@@ -555,7 +601,7 @@ struct Wave {
       const int d = lane + RR_LANES * s;
       lim_act[s] = false; lim_sign[s] = 0; lim_D[s] = 0; lim_aref[s] = 0; lim_jar[s] = 0; lim_jv[s] = 0;
       if (d < D.nv) {
-        const int* di = T.dof_i + 10 * d;
+        const int* di = T.dof_i + RR_DOFI * d;
         if (di[8]) {
           const float* df = T.dof_f + 16 * d;
           const float q = s_qpos[di[6]];
@@ -639,14 +685,22 @@ struct Wave {
           con_jadr[cs] = jadr; con_nanc[cs] = nanc;
           const v3 off = pos - get_com(r);
           float jnv = 0, j1v = 0, j2v = 0;
-          for (int p = 0; p < nanc; ++p) {
-            const int dd = T.con_chain[p * WC + c];
-            const float* cd = s_cdof + 6 * dd;
-            const v3 jp = ld3(cd + 3) + cross(ld3(cd), off);
-            const float jn = dot(n, jp), j1 = dot(fb, jp), j2 = dot(fc, jp);
-            s_J[jadr + 3 * p] = jn; s_J[jadr + 3 * p + 1] = j1; s_J[jadr + 3 * p + 2] = j2;
-            const float qv = s_qvel[dd];
-            jnv += jn * qv; j1v += j1 * qv; j2v += j2 * qv;
+          for (int p0 = 0; p0 < nanc; p0 += RR_U) {
+            int ddv[RR_U];
+#pragma unroll
+            for (int u = 0; u < RR_U; ++u) ddv[u] = T.con_chain[(p0 + u) * WC + c];
+#pragma unroll
+            for (int u = 0; u < RR_U; ++u) {
+              const int dd = ddv[u], p = p0 + u;
+              if (dd >= 0) {
+                const float* cd = s_cdof + 6 * dd;
+                const v3 jp = ld3(cd + 3) + cross(ld3(cd), off);
+                const float jn = dot(n, jp), j1 = dot(fb, jp), j2 = dot(fc, jp);
+                s_J[jadr + 3 * p] = jn; s_J[jadr + 3 * p + 1] = j1; s_J[jadr + 3 * p + 2] = j2;
+                const float qv = s_qvel[dd];
+                jnv += jn * qv; j1v += j1 * qv; j2v += j2 * qv;
+              }
+            }
           }
           const float kk = k * imp * dist;
           con_aref[cs][0] = -bcoef * (jnv + mu * j1v) - kk;
@@ -673,9 +727,18 @@ struct Wave {
         const int c = lane + RR_LANES * cs;
         float jn = 0, j1 = 0, j2 = 0;
         const int jadr = con_jadr[cs];
-        for (int p = 0; p < con_nanc[cs]; ++p) {
-          const float xv = s_vec[T.con_chain[p * WC + c]];
-          jn += s_J[jadr + 3 * p] * xv; j1 += s_J[jadr + 3 * p + 1] * xv; j2 += s_J[jadr + 3 * p + 2] * xv;
+        for (int p0 = 0; p0 < con_nanc[cs]; p0 += RR_U) {
+          int ddv[RR_U];
+#pragma unroll
+          for (int u = 0; u < RR_U; ++u) ddv[u] = T.con_chain[(p0 + u) * WC + c];
+#pragma unroll
+          for (int u = 0; u < RR_U; ++u) {
+            if (ddv[u] >= 0) {
+              const float xv = s_vec[ddv[u]];
+              const int p = p0 + u;
+              jn += s_J[jadr + 3 * p] * xv; j1 += s_J[jadr + 3 * p + 1] * xv; j2 += s_J[jadr + 3 * p + 2] * xv;
+            }
+          }
         }
         const float mu = con_mu[cs];
         out[cs][0] = jn + mu * j1; out[cs][1] = jn - mu * j1; out[cs][2] = jn + mu * j2; out[cs][3] = jn - mu * j2;
@@ -715,16 +778,23 @@ struct Wave {
       part[1] += (Ma[s] - qfrc_smooth[s]) * (qacc[s] - qacc_smooth[s]);
     }
     sync();
-    for (int t = 0; t < D.T_jtf; ++t) {
+    for (int t0 = 0; t0 < D.T_jtf; t0 += RR_U) {
+      int ev[RR_U][NVS];
 #pragma unroll
-      for (int s = 0; s < NVS; ++s) {
-        const int e = T.jtf[t * W + s * RR_LANES + lane];
-        if (e >= 0) {
-          const int c = e & 255, adr = e >> 8;
-          if (con_bit(c))
-            qfrc_con[s] += s_J[adr] * s_cf[3 * c] + s_J[adr + 1] * s_cf[3 * c + 1] + s_J[adr + 2] * s_cf[3 * c + 2];
+      for (int u = 0; u < RR_U; ++u)
+#pragma unroll
+        for (int s = 0; s < NVS; ++s) ev[u][s] = T.jtf[(t0 + u) * W + s * RR_LANES + lane];
+#pragma unroll
+      for (int u = 0; u < RR_U; ++u)
+#pragma unroll
+        for (int s = 0; s < NVS; ++s) {
+          const int e = ev[u][s];
+          if (e >= 0) {
+            const int c = e & 255, adr = e >> 8;
+            if (con_bit(c))
+              qfrc_con[s] += s_J[adr] * s_cf[3 * c] + s_J[adr + 1] * s_cf[3 * c + 1] + s_J[adr + 2] * s_cf[3 * c + 2];
+          }
         }
-      }
     }
     wave_sum_n<2>(part);
     gauss = 0.5f * part[1];
@@ -911,7 +981,7 @@ struct Wave {
     for (int s = 0; s < NVS; ++s) {
       const int d = lane + RR_LANES * s;
       if (d < D.nv) {
-        const int u = T.dof_i[10 * d + 7];
+        const int u = T.dof_i[RR_DOFI * d + 7];
         if (u >= 0) s_act[u] += D.dt * act_dot[s];
         s_qvel[d] += D.dt * qa[s];
       }
@@ -921,7 +991,7 @@ struct Wave {
     for (int s = 0; s < NVS; ++s) {
       const int d = lane + RR_LANES * s;
       if (d < D.nv) {
-        const int kind = T.dof_i[10 * d + 2], qadr = T.dof_i[10 * d + 6];
+        const int kind = T.dof_i[RR_DOFI * d + 2], qadr = T.dof_i[RR_DOFI * d + 6];
         if (kind == 6 || kind < 3) {
           s_qpos[qadr] += D.dt * s_qvel[d];
         } else if (kind == 3) {  // quaternion of the free joint: q <- normalize(q * exp(dt*w/2)), w in the body frame
@@ -964,9 +1034,13 @@ __global__ __launch_bounds__(RR_LANES) void rr_step_kernel(const RRDims D, const
   for (int s = 0; s < NVS; ++s) {
     const int d = lane + RR_LANES * s;
     w.warm[s] = d < D.nv ? io.warm[(size_t)env * D.nv + d] : 0.0f;
-    w.dofdepth[s] = d < D.nv ? T.dof_i[10 * d + 3] : -1;
+    w.dofdepth[s] = d < D.nv ? T.dof_i[RR_DOFI * d + 3] : -1;
+    w.dofmadr[s] = d < D.nv ? T.dof_i[RR_DOFI * d + 4] : 0;
+    w.doflast[s] = d < D.nv ? T.dof_i[RR_DOFI * d + 10] : -1;
     w.qacc[s] = w.Ma[s] = w.grad[s] = w.Mgrad[s] = w.search[s] = w.mv[s] = w.qfrc_con[s] = 0.0f;
   }
+#pragma unroll
+  for (int i = 0; i < Wave<NBS, NVS, NCS>::RR_TRI; ++i) { const int t = lane + RR_LANES * i; w.tri_r[i] = t < D.ntri ? T.tri[t] : 0; }
   if (lane == 0) {  // world body
     for (int k = 0; k < 3; ++k) w.s_xpos[k] = 0.0f;
     w.s_xquat[0] = 1.0f; w.s_xquat[1] = w.s_xquat[2] = w.s_xquat[3] = 0.0f;

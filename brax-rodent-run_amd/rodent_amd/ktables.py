@@ -15,6 +15,7 @@ from __future__ import annotations
 import numpy as np
 
 LANES = 64
+UNROLL = 8      # the kernel consumes lane tables in batches of 8 rows (loads issued together)
 
 
 def _slots(n):
@@ -89,8 +90,18 @@ def build_kernel_tables(m):
         if m["jnt_limited"][j]:
             lim[m["jnt_dofadr"][j]] = 1
     jid = m["dof_jntid"]
+    last_desc = np.arange(nv, dtype=np.int32)
+    for d in range(nv - 1, -1, -1):
+        if dpar[d] >= 0:
+            last_desc[dpar[d]] = max(last_desc[dpar[d]], last_desc[d])
+    for d in range(nv):                                   # dofs must be in DFS preorder (MuJoCo order)
+        p = dpar[d]
+        while p >= 0:
+            assert p < d <= last_desc[p]
+            p = dpar[p]
     k["k_dof_i"] = np.stack([m["dof_bodyid"], jid, kind, ddepth, Madr, dpar, dof_qposadr, act_of_dof, lim,
-                             k["k_body_root"][m["dof_bodyid"]]], axis=1).astype(np.int32)       # 10 ints
+                             k["k_body_root"][m["dof_bodyid"]], last_desc, np.zeros(nv, np.int32)],
+                            axis=1).astype(np.int32)                                           # 12 ints
     hinge = (kind == 6)
     k["k_dof_f"] = np.stack([
         m["dof_armature"], m["dof_damping"], np.where(hinge, m["jnt_stiffness"][jid], 0.0),
@@ -124,6 +135,7 @@ def build_kernel_tables(m):
     def lane_table(rows):
         """rows[d] = list of packed ints for dof d -> [T][W] table padded with -1."""
         T = max(1, max((len(r) for r in rows), default=1))
+        T = (T + UNROLL - 1) // UNROLL * UNROLL
         out = np.full((T, W), -1, np.int32)
         for d, r in enumerate(rows):
             for t, v in enumerate(r):
@@ -157,10 +169,11 @@ def build_kernel_tables(m):
         for l in range(ddepth[i]):
             j = int(chain[l])
             desc_by_level[ddepth[i]][j].append(i | ((Madr[i] + (ddepth[i] - l)) << 8))
-    bwd_rows, bwd_adr = [], [0]
+    bwd_rows, bwd_adr, bwd_level = [], [0], []
     for l in range(dmax, 0, -1):
         T = max(len(r) for r in desc_by_level[l])
         for t in range(T):
+            bwd_level.append(l if t == 0 else -1)
             row = np.full(W, -1, np.int32)
             for j in range(nv):
                 if t < len(desc_by_level[l][j]):
@@ -169,6 +182,7 @@ def build_kernel_tables(m):
         bwd_adr.append(len(bwd_rows))
     k["k_solve_bwd"] = np.stack(bwd_rows) if bwd_rows else np.full((1, W), -1, np.int32)
     k["k_solve_bwd_adr"] = np.asarray(bwd_adr, np.int32)     # entry i: first row of level dmax-i
+    k["k_solve_bwd_level"] = np.asarray(bwd_level if bwd_level else [-1], np.int32)  # level published before row r, or -1
 
     # ---- contacts
     WC = NCS * LANES
@@ -190,7 +204,7 @@ def build_kernel_tables(m):
         m["con_solref"].reshape(ncon, 2), m["con_solimp"].reshape(ncon, 5), np.zeros((ncon, 1))], axis=1)  # 26 floats
     # chain of ancestor dofs per contact, [p][lane], leaf first so shallow chains end early
     maxc = int(nanc.max()) if ncon else 1
-    chain_tab = np.full((max(1, maxc), WC), -1, np.int32)
+    chain_tab = np.full(((max(1, maxc) + UNROLL - 1) // UNROLL * UNROLL, WC), -1, np.int32)
     rows = [[] for _ in range(nv)]                     # J^T f gather lists per dof
     for c in range(ncon):
         d = int(lastdof[c])
