@@ -56,6 +56,15 @@ class Rodent(PipelineEnv):
         self._healthy_z_range = healthy_z_range
         self._reset_noise_scale = reset_noise_scale
         self._vision = vision
+        self._ctor = dict(track_pos=track_pos, forward_reward_weight=forward_reward_weight, ctrl_cost_weight=ctrl_cost_weight,
+                          healthy_reward=healthy_reward, terminate_when_unhealthy=terminate_when_unhealthy,
+                          healthy_z_range=healthy_z_range, reset_noise_scale=reset_noise_scale, solver=solver,
+                          iterations=iterations, ls_iterations=ls_iterations, vision=vision, xml_path=xml_path,
+                          n_frames=kwargs["n_frames"])
+
+    def with_num_envs(self, num_envs: int, device=None):
+        """A sibling env with another batch size (ppo.train builds its per-rank and eval envs this way)."""
+        return Rodent(num_envs=num_envs, device=device or self.device, **self._ctor)
 
     def _env_io(self, cur_frame, obs, reward=None, done=None, metrics=None):
         return dict(track_pos=self._track_pos, cur_frame=cur_frame, obs=obs, reward=reward, done=done, metrics=metrics,

@@ -14,6 +14,19 @@ import torch
 from .base import PipelineState, State
 
 
+def _tree_map2(fn, a, b):
+    """Apply fn leaf-wise over two identically structured pytrees (dataclass / dict / tensor / None)."""
+    if a is None:
+        return None
+    if torch.is_tensor(a):
+        return fn(a, b)
+    if dataclasses.is_dataclass(a):
+        return type(a)(**{f.name: _tree_map2(fn, getattr(a, f.name), getattr(b, f.name)) for f in dataclasses.fields(a)})
+    if isinstance(a, dict):
+        return {k: _tree_map2(fn, a[k], b[k]) for k in a}
+    raise TypeError(type(a))
+
+
 class Wrapper:
     def __init__(self, env):
         self.env = env
@@ -95,10 +108,7 @@ class AutoResetWrapper(Wrapper):
             d = done.reshape((-1,) + (1,) * (x.dim() - 1))
             return torch.where(d, x, y)
 
-        first = state.info["first_pipeline_state"]
-        ps = state.pipeline_state
-        new_ps = PipelineState(**{f.name: where_done(getattr(first, f.name), getattr(ps, f.name))
-                                  for f in dataclasses.fields(PipelineState)})
+        new_ps = _tree_map2(where_done, state.info["first_pipeline_state"], state.pipeline_state)
         obs = where_done(state.info["first_obs"], state.obs)
         return state.replace(pipeline_state=new_ps, obs=obs)
 

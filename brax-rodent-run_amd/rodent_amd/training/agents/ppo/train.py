@@ -1,0 +1,223 @@
+"""Proximal policy optimization training: the `brax.training.agents.ppo.train.train` entry point the
+reference launcher calls [REF brax_rodent_run_ppo.py:97-114,200-202], with the same keyword
+arguments, schedule arithmetic, callbacks and return value -- on PyTorch-ROCm.
+
+Data parallelism: one process per GPU (launch with torch.distributed.run); `num_envs` / `batch_size`
+are GLOBAL as upstream, each rank steps `num_envs // world_size` environments; the only collectives
+are the per-minibatch gradient all-reduce(mean) on one flat buffer and the normaliser all-reduce(sum)
+once per training step (RCCL over xGMI; gloo in the CPU tests).
+"""
+from __future__ import annotations
+
+import math
+import time
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .... import jax_random
+from ....envs import wrappers
+from ... import acting, distributed as D, networks as ppo_networks_mod, running_statistics
+from . import losses as ppo_losses
+
+
+def _local_env(environment, local_num_envs: int, device):
+    if getattr(environment, "num_envs", None) == local_num_envs:
+        return environment
+    if hasattr(environment, "with_num_envs"):
+        return environment.with_num_envs(local_num_envs, device)
+    raise ValueError(f"environment has {getattr(environment, 'num_envs', '?')} envs, need {local_num_envs} per rank")
+
+
+def train(
+    environment,
+    num_timesteps: int,
+    episode_length: int,
+    action_repeat: int = 1,
+    num_envs: int = 1,
+    max_devices_per_host: Optional[int] = None,
+    num_eval_envs: int = 128,
+    learning_rate: float = 1e-4,
+    entropy_cost: float = 1e-4,
+    discounting: float = 0.9,
+    seed: int = 0,
+    unroll_length: int = 10,
+    batch_size: int = 32,
+    num_minibatches: int = 16,
+    num_updates_per_batch: int = 2,
+    num_evals: int = 1,
+    num_resets_per_eval: int = 0,
+    normalize_observations: bool = False,
+    reward_scaling: float = 1.0,
+    clipping_epsilon: float = 0.3,
+    gae_lambda: float = 0.95,
+    deterministic_eval: bool = False,
+    network_factory: Callable = ppo_networks_mod.make_ppo_networks,
+    progress_fn: Callable = lambda *args: None,
+    normalize_advantage: bool = True,
+    eval_env=None,
+    policy_params_fn: Callable = lambda *args: None,
+    randomization_fn=None,
+    max_training_steps: Optional[int] = None,
+    timing_fn: Optional[Callable] = None,
+):
+    """PPO training.  Returns (make_policy, params=(normalizer_params, policy_params), metrics).
+
+    `max_training_steps` (extension) stops after that many training steps (benchmarks / tests).
+    """
+    assert batch_size * num_minibatches % num_envs == 0
+    if randomization_fn is not None:
+        raise NotImplementedError("domain randomisation is not used by the reference launcher")
+    xt = time.time()
+    process_count, process_id = D.world_size(), D.rank()
+    device_count = process_count                         # one device per process
+    if num_envs % device_count:
+        raise ValueError("num_envs must be divisible by the number of ranks")
+    local_num_envs = num_envs // device_count
+    env_step_per_training_step = batch_size * unroll_length * num_minibatches * action_repeat
+    num_evals_after_init = max(num_evals - 1, 1)
+    num_training_steps_per_epoch = int(np.ceil(
+        num_timesteps / (num_evals_after_init * env_step_per_training_step * max(num_resets_per_eval, 1))))
+
+    env = _local_env(environment, local_num_envs, getattr(environment, "device", None))
+    device = env.device
+    wenv = wrappers.wrap(env, episode_length=episode_length, action_repeat=action_repeat)
+
+    # ---- keys [UP ppo.train]: reset keys follow the jax key tree so initial states match the reference
+    key = jax_random.PRNGKey(seed)
+    global_key, local_key = jax_random.split(key)
+    local_key = jax_random.fold_in(local_key, process_id)
+    local_key, key_env, eval_key = jax_random.split(local_key, 3)
+    key_envs = jax_random.split(key_env, local_num_envs)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(local_key[0]) * 2 ** 32 + int(local_key[1]))
+    torch.manual_seed(int(global_key[0]) * 2 ** 32 + int(global_key[1]))     # identical parameter init on every rank
+    perm_gen = torch.Generator(device="cpu")
+    perm_gen.manual_seed(int(local_key[1]))
+
+    env_state = wenv.reset(key_envs)
+
+    ppo_network = network_factory(env.observation_size, env.action_size, device=device)
+    dist = ppo_network.parametric_action_distribution
+    policy_net, value_net = ppo_network.policy_network, ppo_network.value_network
+    params = list(policy_net.parameters()) + list(value_net.parameters())
+    if process_count > 1:                                # replicate (rank 0's init), like device_put_replicated
+        for p in params:
+            torch.distributed.broadcast(p.data, src=0)
+    flat = D.FlatGrads(params)
+    optimizer = torch.optim.Adam(params, lr=learning_rate, betas=(0.9, 0.999), eps=1e-8)
+    normalizer_params = running_statistics.init_state(env.observation_size, device)
+    normalize = running_statistics.normalize if normalize_observations else (lambda x, y: x)
+    make_policy = ppo_networks_mod.make_inference_fn(ppo_network)
+
+    def current_params():
+        return (normalizer_params if normalize_observations else None, policy_net)
+
+    if eval_env is None and num_evals > 0 and num_eval_envs > 0:
+        eval_env = _local_env(environment, num_eval_envs, device) if hasattr(environment, "with_num_envs") or \
+            getattr(environment, "num_envs", None) == num_eval_envs else None
+    evaluator = None
+    if eval_env is not None:
+        weval = wrappers.wrap(eval_env, episode_length=episode_length, action_repeat=action_repeat)
+        evaluator = acting.Evaluator(weval, lambda p: make_policy(p, deterministic=deterministic_eval), num_eval_envs,
+                                     episode_length, action_repeat, eval_key)
+
+    U = batch_size * num_minibatches // num_envs
+    N, T = local_num_envs, unroll_length
+    buf = acting.UnrollBuffer(U, N, T, env.observation_size, env.action_size, device)
+    local_batch = U * N // num_minibatches               # trajectories per rank per minibatch
+
+    def sync():
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+
+    def training_step():
+        nonlocal env_state, normalizer_params
+        t0 = time.time()
+        policy = make_policy(current_params())
+        for u in range(U):
+            env_state = acting.generate_unroll(wenv, env_state, policy, buf, u, gen)
+        sync()
+        t1 = time.time()
+        data = buf.flat()
+        if normalize_observations:                       # update on `observation` (not next_observation), all ranks
+            normalizer_params = running_statistics.update(normalizer_params, buf.obs[:, :, :T])
+        metrics = {}
+        for _ in range(num_updates_per_batch):
+            perm = torch.randperm(U * N, generator=perm_gen).to(device)
+            for mb in range(num_minibatches):
+                idx = perm[mb * local_batch:(mb + 1) * local_batch]
+                obs = normalize(data["obs"][idx].transpose(0, 1), normalizer_params)     # [T+1, B, obs]
+                mbd = {k: data[k][idx].transpose(0, 1) for k in ("raw_action", "log_prob", "reward", "discount", "truncation")}
+                policy_logits = policy_net(obs[:T])
+                values = value_net(obs).squeeze(-1)
+                loss, metrics = ppo_losses.compute_ppo_loss(
+                    policy_logits, values[:T], values[T], mbd, dist, entropy_cost=entropy_cost, discounting=discounting,
+                    reward_scaling=reward_scaling, gae_lambda=gae_lambda, clipping_epsilon=clipping_epsilon,
+                    normalize_advantage=normalize_advantage, generator=gen)
+                flat.zero_()
+                loss.backward()
+                flat.pmean_()                            # jax.lax.pmean(grads, 'i')
+                optimizer.step()
+        sync()
+        t2 = time.time()
+        if timing_fn is not None:
+            timing_fn({"rollout_s": t1 - t0, "learner_s": t2 - t1, "env_steps": env_step_per_training_step})
+        return {f"training/{k}": float(v) for k, v in metrics.items()}
+
+    metrics = {}
+    if process_id == 0 and evaluator is not None and num_evals > 1:
+        metrics = evaluator.run_evaluation(current_params(), training_metrics={})
+        progress_fn(0, metrics)
+
+    training_metrics = {}
+    training_walltime = 0.0
+    current_step = 0
+    steps_done = 0
+    stop = False
+    for it in range(num_evals_after_init):
+        for _ in range(max(num_resets_per_eval, 1)):
+            t = time.time()
+            for _ in range(num_training_steps_per_epoch):
+                training_metrics = training_step()
+                steps_done += 1
+                if max_training_steps is not None and steps_done >= max_training_steps:
+                    stop = True
+                    break
+            epoch_training_time = time.time() - t
+            training_walltime += epoch_training_time
+            done_steps = steps_done if stop else num_training_steps_per_epoch
+            sps = (min(done_steps, num_training_steps_per_epoch) * env_step_per_training_step) / epoch_training_time
+            training_metrics = {"training/sps": sps, "training/walltime": training_walltime, **training_metrics}
+            current_step = steps_done * env_step_per_training_step
+            if num_resets_per_eval > 0 and not stop:
+                local_key, key_env = jax_random.split(local_key)
+                env_state = wenv.reset(jax_random.split(key_env, local_num_envs))
+            if stop:
+                break
+        if process_id == 0:
+            if evaluator is not None:
+                metrics = evaluator.run_evaluation(current_params(), training_metrics)
+            else:
+                metrics = dict(training_metrics)
+            progress_fn(current_step, metrics)
+            policy_params_fn(current_step, make_policy, params_tuple(normalizer_params, policy_net, normalize_observations))
+        if stop:
+            break
+
+    total_steps = current_step
+    if max_training_steps is None:
+        assert total_steps >= num_timesteps
+    if process_count > 1:                                # pmap.assert_is_replicated / synchronize_hosts
+        chk = torch.stack([p.detach().float().sum() for p in params]).sum().reshape(1)
+        lo, hi = chk.clone(), chk.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        assert torch.allclose(lo, hi, rtol=1e-5, atol=1e-6), "parameters diverged across ranks"
+    return make_policy, params_tuple(normalizer_params, policy_net, normalize_observations), metrics
+
+
+def params_tuple(normalizer_params, policy_net, normalize_observations: bool):
+    """(normalizer_params, policy_params) as the reference's callbacks receive them."""
+    return (normalizer_params if normalize_observations else None, policy_net)

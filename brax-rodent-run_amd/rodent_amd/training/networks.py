@@ -1,0 +1,110 @@
+"""PPO networks of `brax.training.agents.ppo.networks.make_ppo_networks` (defaults): policy MLP
+obs -> 32 x4 -> 2*action_size, value MLP obs -> 256 x5 -> 1, swish on hidden layers,
+lecun_uniform kernels, zero biases; `NormalTanhDistribution(min_std=1e-3)`.
+The GEMMs run on the matrix cores through rocBLAS/hipBLASLt; nothing else in the path uses MFMA."""
+from __future__ import annotations
+
+import math
+from typing import Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class MLP(nn.Module):
+    def __init__(self, in_size: int, layer_sizes: Sequence[int]):
+        super().__init__()
+        sizes = [in_size] + list(layer_sizes)
+        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(sizes[:-1], sizes[1:]))
+        for lin in self.layers:
+            bound = math.sqrt(3.0 / lin.in_features)          # lecun_uniform: variance 1/fan_in
+            nn.init.uniform_(lin.weight, -bound, bound)
+            nn.init.zeros_(lin.bias)
+
+    def forward(self, x):
+        for i, lin in enumerate(self.layers):
+            x = lin(x)
+            if i != len(self.layers) - 1:
+                x = F.silu(x)
+        return x
+
+
+class NormalTanhDistribution:
+    """Normal followed by tanh; parameters = concat(loc, pre-softplus scale)."""
+
+    def __init__(self, event_size: int, min_std: float = 0.001):
+        self.event_size = event_size
+        self.param_size = 2 * event_size
+        self.min_std = min_std
+
+    def _params(self, logits):
+        loc, s = torch.chunk(logits, 2, dim=-1)
+        return loc, F.softplus(s) + self.min_std
+
+    def sample_no_postprocessing(self, logits, generator=None):
+        loc, scale = self._params(logits)
+        eps = torch.randn(loc.shape, device=loc.device, dtype=loc.dtype, generator=generator)
+        return loc + scale * eps
+
+    def mode(self, logits):
+        return torch.tanh(self._params(logits)[0])
+
+    @staticmethod
+    def postprocess(x):
+        return torch.tanh(x)
+
+    @staticmethod
+    def _log_det_jac(x):
+        return 2.0 * (math.log(2.0) - x - F.softplus(-2.0 * x))
+
+    def log_prob(self, logits, raw_actions):
+        loc, scale = self._params(logits)
+        lp = -0.5 * ((raw_actions - loc) / scale) ** 2 - torch.log(scale) - 0.5 * math.log(2 * math.pi)
+        return (lp - self._log_det_jac(raw_actions)).sum(-1)
+
+    def entropy(self, logits, generator=None):
+        loc, scale = self._params(logits)
+        ent = 0.5 + 0.5 * math.log(2 * math.pi) + torch.log(scale)
+        raw = self.sample_no_postprocessing(logits, generator)
+        return (ent + self._log_det_jac(raw)).sum(-1)
+
+
+class PPONetworks:
+    def __init__(self, policy_network: MLP, value_network: MLP, parametric_action_distribution: NormalTanhDistribution):
+        self.policy_network = policy_network
+        self.value_network = value_network
+        self.parametric_action_distribution = parametric_action_distribution
+
+
+def make_ppo_networks(observation_size: int, action_size: int, policy_hidden_layer_sizes=(32,) * 4,
+                      value_hidden_layer_sizes=(256,) * 5, device=None) -> PPONetworks:
+    dist = NormalTanhDistribution(event_size=action_size)
+    policy = MLP(observation_size, list(policy_hidden_layer_sizes) + [dist.param_size]).to(device)
+    value = MLP(observation_size, list(value_hidden_layer_sizes) + [1]).to(device)
+    return PPONetworks(policy, value, dist)
+
+
+def make_inference_fn(ppo_networks: PPONetworks):
+    """`make_policy(params, deterministic)` -> `policy(obs, key) -> (action, extras)` [UP ppo.networks]."""
+    from . import running_statistics
+
+    def make_policy(params, deterministic: bool = False):
+        normalizer_params, policy_params = params[0], params[1]
+        net = ppo_networks.policy_network
+        if policy_params is not None and policy_params is not net:
+            net.load_state_dict(policy_params) if isinstance(policy_params, dict) else None
+        dist = ppo_networks.parametric_action_distribution
+
+        @torch.no_grad()
+        def policy(observations, key_sample=None):
+            x = observations if normalizer_params is None else running_statistics.normalize(observations, normalizer_params)
+            logits = net(x)
+            if deterministic:
+                return dist.mode(logits), {}
+            raw = dist.sample_no_postprocessing(logits, key_sample)
+            return dist.postprocess(raw), {"log_prob": dist.log_prob(logits, raw), "raw_action": raw}
+
+        return policy
+
+    return make_policy

@@ -1,0 +1,31 @@
+"""GPU: one short PPO run on the real Rodent env through `ppo.train` (the launcher's entry point)."""
+import math
+
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ppo_train_on_rodent_env():
+    from rodent_amd import envs
+    from rodent_amd.training.agents.ppo import train as ppo
+    env = envs.get_environment("rodent", track_pos=util.synthetic_track(), num_envs=256, xml_path="rodent_optimized.xml",
+                               iterations=8, ls_iterations=8, device="cuda:0")
+    log, timing = [], []
+    make_policy, params, metrics = ppo.train(
+        environment=env, num_timesteps=256 * 5 * 4, episode_length=150, num_envs=256, batch_size=256, num_minibatches=4,
+        unroll_length=5, num_updates_per_batch=2, num_evals=2, num_eval_envs=32, learning_rate=5e-5, entropy_cost=1e-3,
+        discounting=0.97, normalize_observations=True, seed=0, progress_fn=lambda n, m: log.append((n, m)),
+        timing_fn=timing.append)
+    assert log and log[-1][0] == 256 * 5 * 4
+    m = log[-1][1]
+    for k in ("eval/episode_reward", "eval/episode_pos_reward", "eval/episode_reward_alive", "training/sps",
+              "training/total_loss", "eval/avg_episode_length"):
+        assert k in m and math.isfinite(float(m[k])), k
+    pol = make_policy(params, deterministic=True)
+    act, _ = pol(torch.zeros(2, env.observation_size, device="cuda:0"))
+    assert act.shape == (2, env.action_size) and torch.isfinite(act).all()
+    assert timing and timing[0]["rollout_s"] > 0

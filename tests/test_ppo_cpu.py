@@ -1,0 +1,119 @@
+"""CPU tests of the PPO host logic (losses, normaliser, wrappers, train loop, 2-rank gloo DP)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from rodent_amd.envs import wrappers
+from rodent_amd.training import networks, running_statistics
+from rodent_amd.training.agents.ppo import losses
+from rodent_amd.training.agents.ppo import train as ppo
+from tests.fake_env import PointEnv
+
+
+def test_gae_matches_loop_restatement():
+    """Independent numpy restatement of the upstream GAE recurrence."""
+    rng = np.random.default_rng(0)
+    T, B = 10, 7
+    r, v = rng.normal(size=(T, B)), rng.normal(size=(T, B))
+    boot = rng.normal(size=B)
+    trunc = (rng.random((T, B)) < 0.15).astype(np.float64)
+    done = (rng.random((T, B)) < 0.2).astype(np.float64)
+    term = done * (1 - trunc)
+    g, lam = 0.97, 0.95
+    vs_w = np.zeros((T, B)); adv_w = np.zeros((T, B))
+    for b in range(B):
+        acc = 0.0
+        vs_next = boot[b]
+        for t in range(T - 1, -1, -1):
+            v_next = boot[b] if t == T - 1 else v[t + 1, b]
+            delta = (r[t, b] + g * (1 - term[t, b]) * v_next - v[t, b]) * (1 - trunc[t, b])
+            acc = delta + g * (1 - term[t, b]) * (1 - trunc[t, b]) * lam * acc
+            vs_w[t, b] = acc + v[t, b]
+        for t in range(T):
+            vs_next = boot[b] if t == T - 1 else vs_w[t + 1, b]
+            adv_w[t, b] = (r[t, b] + g * (1 - term[t, b]) * vs_next - v[t, b]) * (1 - trunc[t, b])
+    tt = lambda a: torch.tensor(a, dtype=torch.float64)
+    vs, adv = losses.compute_gae(tt(trunc), tt(term), tt(r), tt(v), tt(boot), lambda_=lam, discount=g)
+    np.testing.assert_allclose(vs.numpy(), vs_w, rtol=1e-12)
+    np.testing.assert_allclose(adv.numpy(), adv_w, rtol=1e-12)
+
+
+def test_tanh_normal_log_prob_and_entropy():
+    d = networks.NormalTanhDistribution(3)
+    logits = torch.randn(5, 6, dtype=torch.float64)
+    raw = torch.randn(5, 3, dtype=torch.float64)
+    loc, s = logits[:, :3], torch.nn.functional.softplus(logits[:, 3:]) + 1e-3
+    base = torch.distributions.Normal(loc, s).log_prob(raw)
+    want = (base - torch.log(1 - torch.tanh(raw) ** 2)).sum(-1)           # change of variables a = tanh(raw)
+    torch.testing.assert_close(d.log_prob(logits, raw), want, rtol=1e-8, atol=1e-8)
+    assert torch.all(d.mode(logits).abs() <= 1)
+
+
+def test_running_statistics_matches_numpy():
+    st = running_statistics.init_state(4, "cpu")
+    rng = np.random.default_rng(1)
+    chunks = [rng.normal(2.0, 3.0, size=(50, 3, 4)) for _ in range(4)]
+    for c in chunks:
+        st = running_statistics.update(st, torch.tensor(c, dtype=torch.float32))
+    allx = np.concatenate([c.reshape(-1, 4) for c in chunks])
+    np.testing.assert_allclose(st.mean.numpy(), allx.mean(0), rtol=1e-4)
+    np.testing.assert_allclose(st.std.numpy(), allx.std(0), rtol=1e-3)
+    assert float(st.count) == allx.shape[0]
+
+
+def test_episode_and_autoreset_wrappers():
+    env = wrappers.wrap(PointEnv(4), episode_length=5, action_repeat=1)
+    keys = np.arange(8, dtype=np.uint32).reshape(4, 2)
+    s = env.reset(keys)
+    first_obs = s.obs.clone()
+    a = torch.zeros(4, 2)
+    for t in range(5):
+        s = env.step(s, a)
+    assert torch.all(s.done == 1) and torch.all(s.info["truncation"] == 1)        # time limit, not termination
+    assert torch.equal(s.obs, first_obs)                                           # auto-reset selects the first state
+    assert torch.all(s.info["cur_frame"] == 5)                                     # info is NOT restored (App. D-7)
+    s = env.step(s, a)
+    assert torch.all(s.info["steps"] == 1) and torch.all(s.done == 0)
+
+
+def test_train_runs_and_learns_on_point_env():
+    rewards = []
+    make_policy, params, metrics = ppo.train(
+        environment=PointEnv(64), num_timesteps=64 * 10 * 4 * 6, episode_length=50, num_envs=64, batch_size=64,
+        num_minibatches=4, unroll_length=10, num_updates_per_batch=2, num_evals=4, num_eval_envs=16, learning_rate=3e-3,
+        normalize_observations=True, seed=0, progress_fn=lambda n, m: rewards.append(m.get("eval/episode_reward")))
+    assert len(rewards) == 4 and all(math.isfinite(r) for r in rewards)
+    assert "training/sps" in metrics and "eval/episode_dist" in metrics
+    pol = make_policy(params, deterministic=True)
+    act, _ = pol(torch.zeros(3, 4))
+    assert act.shape == (3, 2)
+
+
+def _dp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _, params, _ = ppo.train(environment=PointEnv(16), num_timesteps=32 * 5 * 2 * 2, episode_length=20, num_envs=32,
+                                 batch_size=32, num_minibatches=2, unroll_length=5, num_updates_per_batch=2, num_evals=2,
+                                 num_eval_envs=8, normalize_observations=True, seed=3)
+        vec = torch.cat([p.detach().reshape(-1) for p in params[1].parameters()])
+        out[rank] = (vec.numpy().copy(), params[0].mean.numpy().copy(), float(params[0].count))
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_gloo():
+    """world_size 2 over gloo: gradients and normaliser statistics are all-reduced, so both ranks end with
+    identical parameters although their env shards (and reset keys, via fold_in(rank)) differ."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
+    (p0, m0, c0), (p1, m1, c1) = out[0], out[1]
+    np.testing.assert_allclose(p0, p1, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(m0, m1, rtol=0, atol=1e-7)
+    assert c0 == c1 == 32 * 5 * 2 * 2                     # count sums the transitions of BOTH ranks
