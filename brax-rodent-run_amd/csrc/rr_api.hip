@@ -50,7 +50,7 @@ static void layout(rr_model* m) {
   k.o_qM = take(d.nM); k.o_qLD = take(d.nM);
   const int32_t* jadr = (const int32_t*)m->find("con_jadr")->data;
   k.nJ = jadr[d.ncon];
-  k.o_J = take(jadr[d.ncon]); k.o_cf = take(3 * d.ncon); k.o_vec = take(d.nv); k.o_x = take(d.nv);
+  k.o_J = take(jadr[d.ncon]); k.o_cf = take(3 * d.ncon); k.o_vec = take(d.nv); k.o_x = take(d.nv); k.o_y = take(d.nv); k.o_arm = take(2 * d.nv);
   k.lds_floats = o;
   // debug dump
   int g = 0;
@@ -103,7 +103,7 @@ extern "C" int rr_model_load(const char* path, rr_model** out) {
   static const char* need[] = {"nq", "nv", "nu", "nbody", "njnt", "ngeom", "nM", "ncon", "nlimit", "nefc", "obs_dim", "k_slots",
                                "k_lvl_adr", "k_lvl_body", "k_child", "k_body_i", "k_body_f", "k_jnt_i", "k_jnt_f", "k_dof_i",
                                "k_dof_f", "k_act_f", "k_M_ij", "k_M_rowadr", "k_tri", "k_mulm", "k_solve_fwd", "k_solve_bwd",
-                               "k_solve_bwd_adr", "k_solve_bwd_level", "k_con_i", "k_con_f", "k_con_chain", "k_jtf", "k_root_mass", "con_jadr",
+                               "k_solve_bwd_adr", "k_solve_bwd_level", "k_bwd_steps", "k_solve2", "k_solve_seq", "k_factor2", "k_factor2_first", "k_factor2_rows", "k_con_chain_packed", "k_con_i", "k_con_f", "k_con_chain", "k_jtf", "k_root_mass", "con_jadr",
                                "dof_depth", "body_depth", "opt_timestep", "opt_gravity", "stat_meaninertia"};
   for (const char* nme : need)
     if (!m->find(nme)) { std::string s = std::string("rr_model_load: blob lacks '") + nme + "'"; delete m; return fail(RR_EIO, s); }
@@ -126,6 +126,9 @@ extern "C" int rr_model_load(const char* path, rr_model** out) {
   k.dmax = dmax;
   k.nroot = (int)m->find("k_root_mass")->count;
   k.ntri = (int)m->find("k_tri")->count;
+  k.nbwd = (int)m->find("k_bwd_steps")->count;
+  k.nfac = m->iscalar("k_factor2_rows");
+  if (m->find("k_solve2")->dims[1] != m->NVS * RR_LANES) { delete m; return fail(RR_EUNSUPPORTED, "rr_model_load: level-solve table wider than the kernel instance"); }
   k.T_mulm = m->find("k_mulm")->dims[0]; k.T_jtf = m->find("k_jtf")->dims[0]; k.T_chain = m->find("k_con_chain")->dims[0];
   k.obs_dim = d.obs_dim; k.iterations = d.iterations; k.ls_iterations = d.ls_iterations;
   k.dt = d.timestep; k.gx = m->fscalar("opt_gravity", 0); k.gy = m->fscalar("opt_gravity", 1); k.gz = m->fscalar("opt_gravity", 2);
@@ -133,6 +136,11 @@ extern "C" int rr_model_load(const char* path, rr_model** out) {
   k.meaninertia = m->fscalar("stat_meaninertia");
   if (k.nroot > 2) { delete m; return fail(RR_EUNSUPPORTED, "rr_model_load: more than 2 kinematic trees"); }
   if (m->find("k_dof_i")->dims[1] != RR_DOFI) { delete m; return fail(RR_EIO, "rr_model_load: k_dof_i width mismatch (stale blob)"); }
+  if (m->find("k_body_i")->dims[1] != RR_BODYI) { delete m; return fail(RR_EIO, "rr_model_load: k_body_i width mismatch (stale blob)"); }
+  {
+    const int nme = m->NVS == 1 ? 10 : (m->NVS == 2 ? 18 : 35);
+    if (d.nM > RR_LANES * nme || k.nbwd > 2 * RR_LANES) { delete m; return fail(RR_EUNSUPPORTED, "rr_model_load: mass-matrix entries / tree schedule exceed the kernel's register tables"); }
+  }
   if (d.nv > 256 || d.ncon > 256) { delete m; return fail(RR_EUNSUPPORTED, "rr_model_load: nv/ncon above the 8-bit table index"); }
   if (m->find("k_mulm")->dims[1] != m->NVS * RR_LANES || m->find("k_con_chain")->dims[1] != m->NCS * RR_LANES) {
     delete m; return fail(RR_EIO, "rr_model_load: lane-table width mismatch");
@@ -168,6 +176,7 @@ struct rr_batch {
   double total_ms = 0;
   int64_t launches = 0;
   bool pending = false;
+  unsigned long long* prof = nullptr;   // diagnostic phase-cycle buffer (rr_batch_set_profile)
 };
 
 template <typename Tp>
@@ -183,10 +192,11 @@ static int upload(rr_batch* b, const char* name, const Tp** dst) {
 }
 
 typedef void (*kern_t)(const RRDims, const RRTables, const RRIO, const int, const int);
-static kern_t pick_kernel(int nbs, int nvs, int ncs) {
-  if (nbs == 1 && nvs == 1 && ncs == 1) return rr_step_kernel<1, 1, 1>;
-  if (nbs == 2 && nvs == 2 && ncs == 1) return rr_step_kernel<2, 2, 1>;
-  if (nbs == 3 && nvs == 3 && ncs == 2) return rr_step_kernel<3, 3, 2>;
+static kern_t pick_kernel(int nbs, int nvs, int ncs, bool prof = false) {
+  if (prof) return (nbs == 2 && nvs == 2 && ncs == 1) ? rr_step_kernel<2, 2, 1, true> : nullptr;
+  if (nbs == 1 && nvs == 1 && ncs == 1) return rr_step_kernel<1, 1, 1, false>;
+  if (nbs == 2 && nvs == 2 && ncs == 1) return rr_step_kernel<2, 2, 1, false>;
+  if (nbs == 3 && nvs == 3 && ncs == 2) return rr_step_kernel<3, 3, 2, false>;
   return nullptr;
 }
 
@@ -200,7 +210,7 @@ extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t devi
 #define UP(field, name) if ((rc = upload(b, name, &b->T.field))) { rr_batch_destroy(b); return rc; }
   UP(lvl_adr, "k_lvl_adr") UP(lvl_body, "k_lvl_body") UP(child, "k_child") UP(body_i, "k_body_i") UP(jnt_i, "k_jnt_i")
   UP(dof_i, "k_dof_i") UP(M_ij, "k_M_ij") UP(M_rowadr, "k_M_rowadr") UP(tri, "k_tri") UP(mulm, "k_mulm")
-  UP(solve_fwd, "k_solve_fwd") UP(solve_bwd, "k_solve_bwd") UP(solve_bwd_adr, "k_solve_bwd_adr") UP(solve_bwd_level, "k_solve_bwd_level") UP(con_i, "k_con_i")
+  UP(solve_fwd, "k_solve_fwd") UP(solve_bwd, "k_solve_bwd") UP(solve_bwd_adr, "k_solve_bwd_adr") UP(solve_bwd_level, "k_solve_bwd_level") UP(bwd_steps, "k_bwd_steps") UP(solve2, "k_solve2") UP(solve_seq, "k_solve_seq") UP(factor2, "k_factor2") UP(factor2_first, "k_factor2_first") UP(con_chain_packed, "k_con_chain_packed") UP(con_i, "k_con_i")
   UP(con_chain, "k_con_chain") UP(jtf, "k_jtf") UP(body_f, "k_body_f") UP(jnt_f, "k_jnt_f") UP(dof_f, "k_dof_f")
   UP(act_f, "k_act_f") UP(con_f, "k_con_f") UP(root_mass, "k_root_mass")
 #undef UP
@@ -252,7 +262,9 @@ static int launch(rr_batch* b, const rr_state* st, const float* ctrl, int n_fram
   }
   io.mode = mode;
   HIPCHK(hipSetDevice(b->device));
-  kern_t kern = pick_kernel(b->m->NBS, b->m->NVS, b->m->NCS);
+  kern_t kern = pick_kernel(b->m->NBS, b->m->NVS, b->m->NCS, b->prof != nullptr);
+  if (!kern) return fail(RR_EUNSUPPORTED, "launch: no diagnostic kernel instance for this model");
+  io.prof = b->prof;
   RRDims kd = b->kd;
   kd.iterations = b->m->kd.iterations; kd.ls_iterations = b->m->kd.ls_iterations;
   if (b->timing) {
@@ -288,6 +300,18 @@ extern "C" int rr_debug_layout(const rr_batch* b, const char*** names, const int
   if (offsets) *offsets = b->m->dbg_off.data();
   if (sizes) *sizes = b->m->dbg_size.data();
   return (int)b->m->dbg_names.size();
+}
+
+extern "C" int rr_batch_set_profile(rr_batch* b, uint64_t* dev_cycles) {
+  if (!b) return fail(RR_EINVAL, "rr_batch_set_profile: null batch");
+  if (dev_cycles) {
+    kern_t kern = pick_kernel(b->m->NBS, b->m->NVS, b->m->NCS, true);
+    if (!kern) return fail(RR_EUNSUPPORTED, "rr_batch_set_profile: no diagnostic kernel instance for this model");
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, b->m->dims.lds_bytes);
+    if (e != hipSuccess) return fail(RR_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+  }
+  b->prof = (unsigned long long*)dev_cycles;
+  return RR_OK;
 }
 
 extern "C" int rr_batch_set_timing(rr_batch* b, int32_t enable) {

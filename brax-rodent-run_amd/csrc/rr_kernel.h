@@ -18,18 +18,21 @@
 
 #define RR_LANES 64
 #define RR_DOFI 12   // ints per dof in k_dof_i
+#define RR_BODYI 12  // ints per body in k_body_i
+#define RR_PF 4      // table rows kept in flight by the level-parallel factor / solve loops
 #define RR_U 8       // lane tables are consumed in batches of RR_U rows: their loads are issued together
+#define RR_NPH 16    // phases of the diagnostic (s_memtime) build
 #define RR_MINVAL 1e-15f
 #define RR_MINIMP 0.0001f
 #define RR_MAXIMP 0.9999f
 
 struct RRDims {
   int nq, nv, nu, nbody, njnt, nM, ncon, nlevel, dmax, nroot;
-  int T_mulm, T_jtf, T_chain, obs_dim, iterations, ls_iterations, nJ, ntri;
+  int T_mulm, T_jtf, T_chain, obs_dim, iterations, ls_iterations, nJ, ntri, nbwd, nfac;
   float dt, gx, gy, gz, tolerance, ls_tolerance, meaninertia;
   // LDS offsets (floats)
   int o_qpos, o_qvel, o_act, o_ctrl, o_xpos, o_xquat, o_xmat, o_cinert, o_crb, o_cdof, o_cvel, o_cacc, o_cfrc, o_buf,
-      o_qM, o_qLD, o_J, o_cf, o_vec, o_x, lds_floats;
+      o_qM, o_qLD, o_J, o_cf, o_vec, o_x, o_y, o_arm, lds_floats;
   // debug dump offsets (floats)
   int g_xpos, g_xquat, g_xmat, g_com, g_cinert, g_crb, g_cdof, g_cvel, g_cfrc, g_qM, g_qLD, g_dinv, g_bias, g_passive,
       g_actuator, g_smooth, g_qacc_smooth, g_con_dist, g_con_pos, g_con_frame, g_con_D, g_con_aref, g_lim, g_qacc,
@@ -38,7 +41,7 @@ struct RRDims {
 
 struct RRTables {
   const int *lvl_adr, *lvl_body, *child, *body_i, *jnt_i, *dof_i, *M_ij, *M_rowadr, *tri, *mulm, *solve_fwd, *solve_bwd,
-      *solve_bwd_adr, *solve_bwd_level, *con_i, *con_chain, *jtf;
+      *solve_bwd_adr, *solve_bwd_level, *bwd_steps, *con_chain_packed, *solve2, *solve_seq, *factor2, *factor2_first, *con_i, *con_chain, *jtf;
   const float *body_f, *jnt_f, *dof_f, *act_f, *con_f, *root_mass;
 };
 
@@ -53,6 +56,7 @@ struct RRIO {
   float *obs, *reward, *done, *metrics;
   float healthy_reward, ctrl_cost_weight, z_min, z_max;
   int terminate_when_unhealthy;
+  unsigned long long* prof;  // diagnostic build only: [N][RR_NPH] cycle sums per phase
   int mode;  // 0 = forward only (pipeline_init), 1 = step; bit 1 (2) = env epilogue as reset (obs only)
 };
 
@@ -86,7 +90,8 @@ __device__ __forceinline__ v3 mat_vec(const float* m, v3 v) {
 __device__ __forceinline__ void quat_normalize(float* q) {
   float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   if (n < RR_MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
-  q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+  const float inv = 1.0f / n;
+  q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
 }
 // spatial inertia (xx yy zz xy xz yz, m*off(3), m) times motion vector (ang; lin)
 __device__ __forceinline__ void mul_inert_vec(float* res, const float* i, const float* v) {
@@ -118,17 +123,42 @@ __device__ __forceinline__ float dot6(const float* a, const float* b) {
   s += a[1] * b[1]; s += a[2] * b[2]; s += a[3] * b[3]; s += a[4] * b[4]; s += a[5] * b[5];
   return s;
 }
+// Wavefront sum, result in every lane.  Four DPP adds give each 16-lane row its total (no LDS crossbar),
+// then the four row totals are read back with v_readlane and added in a fixed order: deterministic, and
+// ~10 VALU issues instead of six dependent ds_bpermute round trips.
+__device__ __forceinline__ float dpp_add(float v, const int ctrl_tag) {
+  int x = __float_as_int(v), y;
+  switch (ctrl_tag) {
+    case 0: y = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true); break;    // quad_perm [1,0,3,2]
+    case 1: y = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true); break;    // quad_perm [2,3,0,1]
+    case 2: y = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true); break;   // row_half_mirror
+    default: y = __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true); break;  // row_mirror
+  }
+  return v + __int_as_float(y);
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v = dpp_add(v, 0); v = dpp_add(v, 1); v = dpp_add(v, 2); v = dpp_add(v, 3);
+  const int x = __float_as_int(v);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(x, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(x, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(x, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(x, 48));
+  return (r0 + r1) + (r2 + r3);
 }
 template <int K>
 __device__ __forceinline__ void wave_sum_n(float* v) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
+  for (int k = 0; k < K; ++k) v[k] = dpp_add(v[k], 0);
 #pragma unroll
-    for (int k = 0; k < K; ++k) v[k] += __shfl_xor(v[k], o);
+  for (int k = 0; k < K; ++k) v[k] = dpp_add(v[k], 1);
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = dpp_add(v[k], 2);
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = dpp_add(v[k], 3);
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int x = __float_as_int(v[k]);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(x, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(x, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(x, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(x, 48));
+    v[k] = (r0 + r1) + (r2 + r3);
   }
 }
 
@@ -154,6 +184,40 @@ __device__ __forceinline__ void kbi(float dt, float sr0, float sr1, const float*
 
 struct LSPoint { float alpha, cost, d0, d1; };
 
+// Per-body model constants.  Slot 0 (bodies 0..63) lives in registers for the whole launch; bodies >= 64
+// (a handful at most) reload theirs from the L2-resident tables at the tree levels where they are active.
+struct BodyC {
+  int parent, depth, sib, root, dofadr, dofnum, jn;
+  int jtype[3], jqa[3], jda[3];
+  float pos[3], quat[4], ipos[3], iquat[4], mass, inertia[3];
+  float jpos[3][3], jaxis[3][3], jq0[3];
+};
+__device__ __forceinline__ BodyC load_bodyc(const RRTables& T, int b, int nbody) {
+  BodyC c;
+  const bool ok = b >= 1 && b < nbody;
+  const int* bi = T.body_i + RR_BODYI * (ok ? b : 0);
+  const float* bf = T.body_f + 18 * (ok ? b : 0);
+  c.parent = bi[0]; c.dofadr = bi[3]; c.dofnum = bi[4]; c.root = bi[5];
+  c.depth = ok ? bi[8] : -1; c.sib = bi[9]; c.jn = ok ? bi[2] : 0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { c.pos[k] = bf[k]; c.ipos[k] = bf[7 + k]; c.inertia[k] = bf[15 + k]; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { c.quat[k] = bf[3 + k]; c.iquat[k] = bf[10 + k]; }
+  c.mass = bf[14];
+#pragma unroll
+  for (int jj = 0; jj < 3; ++jj) {
+    const bool jok = jj < c.jn;
+    const int j = jok ? bi[1] + jj : 0;
+    const int* ji = T.jnt_i + 4 * j;
+    const float* jf = T.jnt_f + 8 * j;
+    c.jtype[jj] = jok ? ji[0] : 3; c.jqa[jj] = ji[1]; c.jda[jj] = ji[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { c.jpos[jj][k] = jf[k]; c.jaxis[jj][k] = jf[3 + k]; }
+    c.jq0[jj] = jf[6];
+  }
+  return c;
+}
+
 // ------------------------------------------------------------------------------------------ the wave
 template <int NBS, int NVS, int NCS>
 struct Wave {
@@ -162,10 +226,19 @@ struct Wave {
   const int lane;
   float* const lds;
   float *s_qpos, *s_qvel, *s_act, *s_ctrl, *s_xpos, *s_xquat, *s_xmat, *s_cinert, *s_crb, *s_cdof, *s_cvel, *s_cacc,
-      *s_cfrc, *s_buf, *s_qM, *s_qLD, *s_J, *s_cf, *s_vec, *s_x;
+      *s_cfrc, *s_buf, *s_qM, *s_qLD, *s_J, *s_cf, *s_vec, *s_x, *s_y, *s_arm;
   static constexpr int W = NVS * RR_LANES;
   static constexpr int WC = NCS * RR_LANES;
 
+  // ---- model constants held in registers for the whole launch (loaded once, reused by all substeps)
+  BodyC bc0;              // constants of body `lane` (slot 0)
+  int bdepth[NBS], bsib[NBS];   // depth / sibling rank of every slot's body (schedule predicates)
+  int dofbody[NVS], dofkind[NVS], dofroot[NVS], dofqadr[NVS];
+  float dofq0[NVS];
+  static constexpr int NME = NVS == 1 ? 10 : (NVS == 2 ? 18 : 35);   // sparse-M entries per lane (nM <= 64*NME)
+  int ment[NME];          // entry e = lane + 64*it of qM: row i | col j << 8, -1 beyond nM
+  int bwd_step_r[2];      // backward-sweep schedule (level | sibling rank << 8), lane st holds step st
+  int con_chain[NCS][9];  // ancestor dof chain of the contact's body, leaf first, 4 dof ids per register
   // per-dof registers (slot s -> dof lane + 64 s)
   int dofdepth[NVS], dofmadr[NVS], doflast[NVS];
   static constexpr int RR_TRI = 10;   // (p,q) pairs of chains up to depth 35 (630 pairs) live in registers
@@ -183,6 +256,10 @@ struct Wave {
   unsigned long long amask[NCS];
   float com0[3], com1[3];
   float gauss, cost, prev_cost;
+  unsigned long long pt_last, pt[RR_NPH];
+  template <bool PROF> __device__ __forceinline__ void stamp(int i) {
+    if (PROF) { const unsigned long long t = __builtin_readcyclecounter(); pt[i] += t - pt_last; pt_last = t; }
+  }
 
   __device__ Wave(const RRDims& d, const RRTables& t, float* l)
       : D(d), T(t), lane(threadIdx.x), lds(l) {
@@ -190,13 +267,15 @@ struct Wave {
     s_xpos = l + d.o_xpos; s_xquat = l + d.o_xquat; s_xmat = l + d.o_xmat; s_cinert = l + d.o_cinert;
     s_crb = l + d.o_crb; s_cdof = l + d.o_cdof; s_cvel = l + d.o_cvel; s_cacc = l + d.o_cacc; s_cfrc = l + d.o_cfrc;
     s_buf = l + d.o_buf; s_qM = l + d.o_qM; s_qLD = l + d.o_qLD; s_J = l + d.o_J; s_cf = l + d.o_cf;
-    s_vec = l + d.o_vec; s_x = l + d.o_x;
+    s_vec = l + d.o_vec; s_x = l + d.o_x; s_y = l + d.o_y; s_arm = l + d.o_arm;
   }
 
   // One wavefront owns the environment: its LDS instructions execute in program order, so a
   // cross-lane hand-off through LDS needs no s_barrier and no vmcnt/lgkmcnt drain -- only that the
   // compiler keeps the program order of the LDS accesses around this point.
-  __device__ __forceinline__ void sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+  // "memory" keeps the compiler from moving LDS accesses across; lgkmcnt(0) retires this wave's LDS operations
+  // (incl. the float atomics) without draining outstanding global table prefetches (no vmcnt wait).
+  __device__ __forceinline__ void sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
   __device__ __forceinline__ v3 get_com(int r) const {
     return mk3(r ? com1[0] : com0[0], r ? com1[1] : com0[1], r ? com1[2] : com0[2]);
   }
@@ -206,58 +285,82 @@ struct Wave {
     for (int i = 1; i < NCS; ++i) mk = (c >> 6) == i ? amask[i] : mk;
     return (mk >> (c & 63)) & 1ull;
   }
+  // p-th ancestor dof (leaf first) of contact slot cs; p is a compile-time constant after unrolling
+  __device__ __forceinline__ int chain_at(int cs, int p) const { return (con_chain[cs][p >> 2] >> (8 * (p & 3))) & 255; }
   // wave-uniform predicate -> scalar branch
   static __device__ __forceinline__ bool uni(bool p) { return __builtin_amdgcn_readfirstlane((int)p) != 0; }
 
   // ---------------------------------------------------------------- A-1 kinematics (level sweep)
+  // Lane b owns body b for every level; its constants are in registers, so a level costs only the
+  // LDS hand-off from the parent (no table or parameter loads).
   __device__ __forceinline__ void kinematics() {
+    // half-angle sin / cos of every hinge, one joint per lane, before the serial level sweep
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) {
+      const int d = lane + RR_LANES * s;
+      if (d < D.nv && dofkind[s] == 6) {
+        const float ang = s_qpos[dofqadr[s]] - dofq0[s];
+        s_buf[2 * d] = sinf(ang * 0.5f);
+        s_buf[2 * d + 1] = cosf(ang * 0.5f);
+      }
+    }
+    sync();
     for (int L = 1; L <= D.nlevel; ++L) {
-      const int a0 = T.lvl_adr[L], cnt = T.lvl_adr[L + 1] - a0;
-      if (lane < cnt) {
-        const int b = T.lvl_body[a0 + lane];
-        const int* bi = T.body_i + 8 * b;
-        const float* bf = T.body_f + 18 * b;
-        const int p = bi[0];
-        float quat[4], mat[9], pq[4], bq[4];
-        v3 pos = ld3(s_xpos + 3 * p) + mat_vec(s_xmat + 9 * p, ld3(bf));
-        for (int k = 0; k < 4; ++k) { pq[k] = s_xquat[4 * p + k]; bq[k] = bf[3 + k]; }
-        quat_mul(quat, pq, bq);
-        const int ja = bi[1], jn = bi[2];
-        int free_da = -1;
-        for (int jj = 0; jj < jn; ++jj) {
-          const int j = ja + jj;
-          const int* ji = T.jnt_i + 4 * j;
-          const float* jf = T.jnt_f + 8 * j;
-          const int qa = ji[1], da = ji[2];
-          if (ji[0] == 0) {  // free
-            pos = ld3(s_qpos + qa);
-            for (int k = 0; k < 4; ++k) quat[k] = s_qpos[qa + 3 + k];
+#pragma unroll
+      for (int s = 0; s < NBS; ++s) {
+        const bool on = bdepth[s] == L;
+        if (__any(on)) {
+          const BodyC c = s == 0 ? bc0 : load_bodyc(T, lane + RR_LANES * s, D.nbody);
+          if (on) {
+            const int b = lane + RR_LANES * s, p = c.parent;
+            float quat[4], mat[9], pq[4];
+            v3 pos = ld3(s_xpos + 3 * p) + mat_vec(s_xmat + 9 * p, mk3(c.pos[0], c.pos[1], c.pos[2]));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pq[k] = s_xquat[4 * p + k];
+            quat_mul(quat, pq, c.quat);
+            int free_da = -1;
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) {
+              if (jj < c.jn) {
+                const int qa = c.jqa[jj], da = c.jda[jj];
+                if (c.jtype[jj] == 0) {  // free
+                  pos = ld3(s_qpos + qa);
+#pragma unroll
+                  for (int k = 0; k < 4; ++k) quat[k] = s_qpos[qa + 3 + k];
+                  quat_normalize(quat);
+                  free_da = da;
+                } else {  // hinge
+                  const v3 jp = mk3(c.jpos[jj][0], c.jpos[jj][1], c.jpos[jj][2]);
+                  const v3 ja = mk3(c.jaxis[jj][0], c.jaxis[jj][1], c.jaxis[jj][2]);
+                  quat_to_mat(mat, quat);
+                  const v3 anchor = mat_vec(mat, jp) + pos;
+                  const v3 axis = mat_vec(mat, ja);
+                  st3(s_cdof + 6 * da, axis);        // raw: axis ; anchor (finalised in com_pos)
+                  st3(s_cdof + 6 * da + 3, anchor);
+                  const float sn = s_buf[2 * da], cs = s_buf[2 * da + 1];
+                  float ql[4] = {cs, ja.x * sn, ja.y * sn, ja.z * sn}, qn[4];
+                  quat_mul(qn, quat, ql);
+#pragma unroll
+                  for (int k = 0; k < 4; ++k) quat[k] = qn[k];
+                  quat_to_mat(mat, quat);
+                  pos = anchor - mat_vec(mat, jp);
+                }
+              }
+            }
             quat_normalize(quat);
-            free_da = da;
-          } else {  // hinge
             quat_to_mat(mat, quat);
-            v3 anchor = mat_vec(mat, ld3(jf)) + pos;
-            v3 axis = mat_vec(mat, ld3(jf + 3));
-            st3(s_cdof + 6 * da, axis);        // raw: axis ; anchor (finalised in com_pos)
-            st3(s_cdof + 6 * da + 3, anchor);
-            const float ang = s_qpos[qa] - jf[6];
-            const float sn = sinf(ang * 0.5f), cs = cosf(ang * 0.5f);
-            float ql[4] = {cs, jf[3] * sn, jf[4] * sn, jf[5] * sn}, qn[4];
-            quat_mul(qn, quat, ql);
-            for (int k = 0; k < 4; ++k) quat[k] = qn[k];
-            quat_to_mat(mat, quat);
-            pos = anchor - mat_vec(mat, ld3(jf));
-          }
-        }
-        quat_normalize(quat);
-        quat_to_mat(mat, quat);
-        st3(s_xpos + 3 * b, pos);
-        for (int k = 0; k < 4; ++k) s_xquat[4 * b + k] = quat[k];
-        for (int k = 0; k < 9; ++k) s_xmat[9 * b + k] = mat[k];
-        if (free_da >= 0) {
-          for (int k = 0; k < 3; ++k) {
-            st3(s_cdof + 6 * (free_da + 3 + k), mk3(mat[k], mat[3 + k], mat[6 + k]));
-            st3(s_cdof + 6 * (free_da + 3 + k) + 3, pos);
+            st3(s_xpos + 3 * b, pos);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s_xquat[4 * b + k] = quat[k];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) s_xmat[9 * b + k] = mat[k];
+            if (free_da >= 0) {
+#pragma unroll
+              for (int k = 0; k < 3; ++k) {
+                st3(s_cdof + 6 * (free_da + 3 + k), mk3(mat[k], mat[3 + k], mat[6 + k]));
+                st3(s_cdof + 6 * (free_da + 3 + k) + 3, pos);
+              }
+            }
           }
         }
       }
@@ -273,14 +376,14 @@ struct Wave {
     for (int s = 0; s < NBS; ++s) {
       const int b = lane + RR_LANES * s;
       xip[s][0] = xip[s][1] = xip[s][2] = 0;
+      if (s > 0 && !__any(b >= 1 && b < D.nbody)) continue;
+      const BodyC c = s == 0 ? bc0 : load_bodyc(T, b, D.nbody);
       if (b >= 1 && b < D.nbody) {
-        const float* bf = T.body_f + 18 * b;
-        v3 xi = ld3(s_xpos + 3 * b) + mat_vec(s_xmat + 9 * b, ld3(bf + 7));
+        v3 xi = ld3(s_xpos + 3 * b) + mat_vec(s_xmat + 9 * b, mk3(c.ipos[0], c.ipos[1], c.ipos[2]));
         xip[s][0] = xi.x; xip[s][1] = xi.y; xip[s][2] = xi.z;
-        const float mass = bf[14];
-        const int r = T.body_i[8 * b + 5];
-        if (r == 0) { acc[0][0] += mass * xi.x; acc[0][1] += mass * xi.y; acc[0][2] += mass * xi.z; }
-        else        { acc[1][0] += mass * xi.x; acc[1][1] += mass * xi.y; acc[1][2] += mass * xi.z; }
+        const float mass = c.mass;
+        if (c.root == 0) { acc[0][0] += mass * xi.x; acc[0][1] += mass * xi.y; acc[0][2] += mass * xi.z; }
+        else                { acc[1][0] += mass * xi.x; acc[1][1] += mass * xi.y; acc[1][2] += mass * xi.z; }
       }
     }
     wave_sum_n<6>(&acc[0][0]);
@@ -291,18 +394,20 @@ struct Wave {
 #pragma unroll
     for (int s = 0; s < NBS; ++s) {
       const int b = lane + RR_LANES * s;
+      if (s > 0 && !__any(b >= 1 && b < D.nbody)) continue;
+      const BodyC c = s == 0 ? bc0 : load_bodyc(T, b, D.nbody);
       if (b >= 1 && b < D.nbody) {
-        const float* bf = T.body_f + 18 * b;
-        const int r = T.body_i[8 * b + 5];
-        float q[4], bq[4], iq[4], R[9];
-        for (int k = 0; k < 4; ++k) { bq[k] = s_xquat[4 * b + k]; iq[k] = bf[10 + k]; }
-        quat_mul(q, bq, iq);
+        float q[4], bq[4], R[9];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bq[k] = s_xquat[4 * b + k];
+        quat_mul(q, bq, c.iquat);
         quat_to_mat(R, q);
-        const float mass = bf[14];
-        const float I0 = bf[15], I1 = bf[16], I2 = bf[17];
-        const v3 cm = get_com(r);
+        const float mass = c.mass;
+        const float I0 = c.inertia[0], I1 = c.inertia[1], I2 = c.inertia[2];
+        const v3 cm = get_com(c.root);
         const float d0 = xip[s][0] - cm.x, d1 = xip[s][1] - cm.y, d2 = xip[s][2] - cm.z;
         float t[9];
+#pragma unroll
         for (int rr = 0; rr < 3; ++rr) { t[3 * rr] = R[3 * rr] * I0; t[3 * rr + 1] = R[3 * rr + 1] * I1; t[3 * rr + 2] = R[3 * rr + 2] * I2; }
         float* c = s_cinert + 10 * b;
         c[0] = t[0] * R[0] + t[1] * R[1] + t[2] * R[2] + mass * (d1 * d1 + d2 * d2);
@@ -319,14 +424,14 @@ struct Wave {
     for (int s = 0; s < NVS; ++s) {
       const int d = lane + RR_LANES * s;
       if (d < D.nv) {
-        const int kind = T.dof_i[RR_DOFI * d + 2], r = T.dof_i[RR_DOFI * d + 9];
+        const int kind = dofkind[s];
         float* c = s_cdof + 6 * d;
         if (kind < 3) {
           c[0] = c[1] = c[2] = 0;
           c[3] = kind == 0; c[4] = kind == 1; c[5] = kind == 2;
         } else {
           v3 ax = ld3(c);
-          v3 off = get_com(r) - ld3(c + 3);
+          v3 off = get_com(dofroot[s]) - ld3(c + 3);
           st3(c + 3, cross(ax, off));
         }
       }
@@ -337,71 +442,79 @@ struct Wave {
   // ---------------------------------------------------------------- A-6 com_vel + rne forward part (level sweep)
   __device__ __forceinline__ void velocity_sweep() {
     for (int L = 1; L <= D.nlevel; ++L) {
-      const int a0 = T.lvl_adr[L], cnt = T.lvl_adr[L + 1] - a0;
-      if (lane < cnt) {
-        const int b = T.lvl_body[a0 + lane];
-        const int* bi = T.body_i + 8 * b;
-        const int p = bi[0], da = bi[3], dn = bi[4];
-        float v[6], a[6];
-        for (int k = 0; k < 6; ++k) { v[k] = s_cvel[6 * p + k]; a[k] = s_cacc[6 * p + k]; }
-        const bool is_free = bi[2] > 0 && T.jnt_i[4 * bi[1]] == 0;
-        if (is_free) {
-          for (int k = 0; k < 3; ++k) {
-            const float qv = s_qvel[da + k];
-            for (int i = 0; i < 6; ++i) v[i] += s_cdof[6 * (da + k) + i] * qv;
+#pragma unroll
+      for (int s = 0; s < NBS; ++s) {
+        const bool on = bdepth[s] == L;
+        if (__any(on)) {
+          const BodyC c = s == 0 ? bc0 : load_bodyc(T, lane + RR_LANES * s, D.nbody);
+          if (on) {
+            const int b = lane + RR_LANES * s, p = c.parent, da = c.dofadr, dn = c.dofnum;
+            float v[6], a[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { v[k] = s_cvel[6 * p + k]; a[k] = s_cacc[6 * p + k]; }
+            const bool is_free = c.jn > 0 && c.jtype[0] == 0;
+            if (is_free) {
+              for (int k = 0; k < 3; ++k) {
+                const float qv = s_qvel[da + k];
+                for (int i = 0; i < 6; ++i) v[i] += s_cdof[6 * (da + k) + i] * qv;
+              }
+              float cd[3][6];
+              for (int k = 0; k < 3; ++k) cross_motion(cd[k], v, s_cdof + 6 * (da + 3 + k));
+              for (int k = 0; k < 3; ++k) {
+                const float qv = s_qvel[da + 3 + k];
+                for (int i = 0; i < 6; ++i) v[i] += s_cdof[6 * (da + 3 + k) + i] * qv;
+              }
+              for (int k = 0; k < 3; ++k) {
+                const float qv = s_qvel[da + 3 + k];
+                for (int i = 0; i < 6; ++i) a[i] += cd[k][i] * qv;
+              }
+            } else {
+              for (int k = 0; k < dn; ++k) {
+                float cd[6];
+                cross_motion(cd, v, s_cdof + 6 * (da + k));
+                const float qv = s_qvel[da + k];
+                for (int i = 0; i < 6; ++i) { v[i] += s_cdof[6 * (da + k) + i] * qv; a[i] += cd[i] * qv; }
+              }
+            }
+            float t[6], t1[6], t2[6];
+            mul_inert_vec(t, s_cinert + 10 * b, v);
+            cross_force(t1, v, t);
+            mul_inert_vec(t2, s_cinert + 10 * b, a);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+              s_cvel[6 * b + k] = v[k];
+              s_cacc[6 * b + k] = a[k];
+              s_cfrc[6 * b + k] = t2[k] + t1[k];
+            }
           }
-          float cd[3][6];
-          for (int k = 0; k < 3; ++k) cross_motion(cd[k], v, s_cdof + 6 * (da + 3 + k));
-          for (int k = 0; k < 3; ++k) {
-            const float qv = s_qvel[da + 3 + k];
-            for (int i = 0; i < 6; ++i) v[i] += s_cdof[6 * (da + 3 + k) + i] * qv;
-          }
-          for (int k = 0; k < 3; ++k) {
-            const float qv = s_qvel[da + 3 + k];
-            for (int i = 0; i < 6; ++i) a[i] += cd[k][i] * qv;
-          }
-        } else {
-          for (int k = 0; k < dn; ++k) {
-            float cd[6];
-            cross_motion(cd, v, s_cdof + 6 * (da + k));
-            const float qv = s_qvel[da + k];
-            for (int i = 0; i < 6; ++i) { v[i] += s_cdof[6 * (da + k) + i] * qv; a[i] += cd[i] * qv; }
-          }
-        }
-        float t[6], t1[6], t2[6];
-        mul_inert_vec(t, s_cinert + 10 * b, v);
-        cross_force(t1, v, t);
-        mul_inert_vec(t2, s_cinert + 10 * b, a);
-        for (int k = 0; k < 6; ++k) {
-          s_cvel[6 * b + k] = v[k];
-          s_cacc[6 * b + k] = a[k];
-          s_cfrc[6 * b + k] = t2[k] + t1[k];
         }
       }
       sync();
     }
   }
 
-  // ---------------------------------------------------------------- crb + cfrc backward accumulation (level sweep)
+  // ---------------------------------------------------------------- crb + cfrc backward accumulation
+  // Scheduled by (level, sibling rank): at each step every selected body adds itself into its parent;
+  // siblings take turns (largest id first = the reference's accumulation order), so no two lanes touch
+  // the same parent in one step.
   __device__ __forceinline__ void backward_sweep() {
     for (int e = lane; e < 10 * D.nbody; e += RR_LANES) s_crb[e] = s_cinert[e];
     sync();
-    for (int L = D.nlevel - 1; L >= 1; --L) {
-      const int a0 = T.lvl_adr[L], cnt = T.lvl_adr[L + 1] - a0;
-      if (lane < cnt) {
-        const int b = T.lvl_body[a0 + lane];
-        const int ca = T.body_i[8 * b + 6], cn = T.body_i[8 * b + 7];
-        if (cn > 0) {
-          float cr[10], cf[6];
-          for (int k = 0; k < 10; ++k) cr[k] = s_crb[10 * b + k];
-          for (int k = 0; k < 6; ++k) cf[k] = s_cfrc[6 * b + k];
-          for (int ci = cn - 1; ci >= 0; --ci) {  // descending child id = the reference's accumulation order
-            const int c = T.child[ca + ci];
-            for (int k = 0; k < 10; ++k) cr[k] += s_crb[10 * c + k];
-            for (int k = 0; k < 6; ++k) cf[k] += s_cfrc[6 * c + k];
+    for (int st = 0; st < D.nbwd; ++st) {
+      const int code = st < RR_LANES ? __builtin_amdgcn_readlane(bwd_step_r[0], st & 63) : __builtin_amdgcn_readlane(bwd_step_r[1], st & 63);
+      const int L = code & 255, r = code >> 8;
+#pragma unroll
+      for (int s = 0; s < NBS; ++s) {
+        const bool on = bdepth[s] == L && bsib[s] == r;
+        if (__any(on)) {
+          const int pp = s == 0 ? bc0.parent : T.body_i[RR_BODYI * min(lane + RR_LANES * s, D.nbody - 1)];
+          if (on) {
+            const int b = lane + RR_LANES * s, p = pp;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) s_crb[10 * p + k] += s_crb[10 * b + k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s_cfrc[6 * p + k] += s_cfrc[6 * b + k];
           }
-          for (int k = 0; k < 10; ++k) s_crb[10 * b + k] = cr[k];
-          for (int k = 0; k < 6; ++k) s_cfrc[6 * b + k] = cf[k];
         }
       }
       sync();
@@ -413,22 +526,27 @@ struct Wave {
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
       const int d = lane + RR_LANES * s;
-      if (d < D.nv) mul_inert_vec(s_buf + 6 * d, s_crb + 10 * T.dof_i[RR_DOFI * d], s_cdof + 6 * d);
+      if (d < D.nv) mul_inert_vec(s_buf + 6 * d, s_crb + 10 * dofbody[s], s_cdof + 6 * d);
     }
     sync();
-    for (int e = lane; e < D.nM; e += RR_LANES) {
-      const int ij = T.M_ij[e], i = ij & 0xffff, j = ij >> 16;
-      float v = dot6(s_cdof + 6 * j, s_buf + 6 * i);
-      if (i == j) v = T.dof_f[16 * i] + v;
-      s_qM[e] = v;
+#pragma unroll
+    for (int it = 0; it < NME; ++it) {
+      const int ij = ment[it];
+      if (ij >= 0) {
+        const int i = ij & 255, j = ij >> 8;
+        float v = dot6(s_cdof + 6 * j, s_buf + 6 * i);
+        if (i == j) v = s_arm[i] + v;
+        s_qM[lane + RR_LANES * it] = v;
+      }
     }
     sync();
   }
 
   // sparse L'DL in place in s_qLD  [MuJoCo mj_factorM]; damp = dt for the eulerdamp matrix M + dt*diag(damping).
-  // No global loads inside the k loop: (p,q) pair indices live in registers (tri_r), the row metadata of
-  // dof k comes from its owner lane by v_readlane, and the row address of each ancestor of k is published
-  // in a small LDS table indexed by depth (ancestor test: j <= k <= last_desc[j], dofs are in DFS preorder).
+  // Level-parallel: all dofs k of one depth level are eliminated together -- their rows are final (only deeper dofs
+  // update them) and their rank-1 updates of shared ancestor entries are combined with LDS float atomics.  One table
+  // row (k_factor2) = 64 independent (src_p, src_q, dst, pivot) updates; the next row is prefetched while the current
+  // one executes; a level boundary is a single LDS hand-off.  Rows are scaled by 1/D afterwards.
   __device__ __forceinline__ void factor(float damp) {
     for (int e = lane; e < D.nM; e += RR_LANES) s_qLD[e] = s_qM[e];
     sync();
@@ -440,117 +558,117 @@ struct Wave {
       }
       sync();
     }
-    int* s_anc = reinterpret_cast<int*>(s_x);   // s_x is free during the factorisation
-    for (int k = D.nv - 1; k >= 0; --k) {
-      int dk = 0, Mkk = 0;
+    // rows are padded to a multiple of RR_PF; a ring of RR_PF rows is kept in flight so the L2 latency of the
+    // table stream is hidden behind RR_PF-1 rows of LDS work
+    const int2* tab = reinterpret_cast<const int2*>(T.factor2);
+    int2 ring[RR_PF];
+    int fring[RR_PF];
 #pragma unroll
-      for (int s = 0; s < NVS; ++s)
-        if ((k >> 6) == s) { dk = __builtin_amdgcn_readlane(dofdepth[s], k & 63); Mkk = __builtin_amdgcn_readlane(dofmadr[s], k & 63); }
-      if (dk > 0) {
+    for (int u = 0; u < RR_PF; ++u) { ring[u] = tab[u * RR_LANES + lane]; fring[u] = T.factor2_first[u]; }
+    for (int r0 = 0; r0 < D.nfac; r0 += RR_PF) {
 #pragma unroll
-        for (int s = 0; s < NVS; ++s) {
-          const int d = lane + RR_LANES * s;
-          if (d < k && k <= doflast[s]) s_anc[dofdepth[s]] = dofmadr[s];   // strict ancestors of k
+      for (int u = 0; u < RR_PF; ++u) {
+        const int2 e = ring[u];
+        const int first = fring[u];
+        if (r0 + RR_PF < D.nfac) { ring[u] = tab[(r0 + RR_PF + u) * RR_LANES + lane]; fring[u] = T.factor2_first[r0 + RR_PF + u]; }
+        if (first) sync();     // updates of the deeper level must have landed
+        if (e.x >= 0) {
+          const int a = e.x & 4095, bq = e.x >> 12, dst = e.y & 4095, piv = e.y >> 12;
+          const float tmp = s_qLD[a] * (1.0f / s_qLD[piv]);
+          atomicAdd(s_qLD + dst, -(s_qLD[bq] * tmp));
         }
-        const float dkk = s_qLD[Mkk];
-        sync();
-        const int npairs = dk * (dk + 1) / 2;
-#pragma unroll
-        for (int i = 0; i < RR_TRI; ++i) {
-          const int t = lane + RR_LANES * i;
-          if (t < npairs) {
-            const int pq = tri_r[i], p = pq & 255, q = pq >> 8;
-            const float tmp = s_qLD[Mkk + p] / dkk;
-            const int adr = s_anc[dk - p] + (q - p);
-            s_qLD[adr] -= s_qLD[Mkk + q] * tmp;
-          }
-        }
-        for (int t = lane + RR_LANES * RR_TRI; t < npairs; t += RR_LANES) {   // deeper trees than the register table
-          const int pq = T.tri[t], p = pq & 255, q = pq >> 8;
-          const float tmp = s_qLD[Mkk + p] / dkk;
-          const int adr = s_anc[dk - p] + (q - p);
-          s_qLD[adr] -= s_qLD[Mkk + q] * tmp;
-        }
-        sync();
-        for (int p = lane + 1; p <= dk; p += RR_LANES) s_qLD[Mkk + p] = s_qLD[Mkk + p] / dkk;
-        sync();
       }
     }
+    sync();
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
       const int d = lane + RR_LANES * s;
       dinv[s] = d < D.nv ? 1.0f / s_qLD[dofmadr[s]] : 0.0f;
+      if (d < D.nv) s_arm[D.nv + d] = dinv[s];   // s_arm[nv..2nv): 1/D per dof for the row scaling below
     }
+    sync();
+#pragma unroll
+    for (int it = 0; it < NME; ++it) {
+      const int ij = ment[it];
+      if (ij >= 0) {
+        const int i = ij & 255, j = ij >> 8;
+        if (i != j) s_qLD[lane + RR_LANES * it] *= s_arm[D.nv + i];
+      }
+    }
+    sync();
   }
 
-  // x <- (L' D L)^-1 x, level-synchronous  [MuJoCo mj_solveLD].  The table row of the NEXT step is
-  // loaded before the LDS hand-off of the current one, so its global-load latency is hidden.
+  // x <- (L' D L)^-1 x  [MuJoCo mj_solveLD], level-parallel: row `l` of k_solve2 holds every entry (i, j) of the dofs
+  // i of depth l+1 side by side on the lanes.  Backward pass (L^-T), deep -> shallow: x_j -= L_ij x_i; forward pass
+  // (L^-1), shallow -> deep: x_i -= L_ij x_j; both as LDS float atomics on the vector in s_x.  2*dmax LDS hand-offs
+  // per solve instead of one per (level, descendant) row; the next table row is prefetched.
   __device__ __forceinline__ void ldl_solve(float* x) {
-    const int nrows = T.solve_bwd_adr[D.dmax];
-    int en[NVS], lvn = T.solve_bwd_level[0];
+    constexpr int W2 = NVS * RR_LANES;
 #pragma unroll
-    for (int s = 0; s < NVS; ++s) en[s] = T.solve_bwd[s * RR_LANES + lane];
-    for (int r = 0; r < nrows; ++r) {
-      int e[NVS];
-      const int lv = lvn;
+    for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; if (d < D.nv) s_x[d] = x[s]; }
+    // k_solve_seq: dmax backward rows (deep -> shallow), then dmax forward rows (shallow -> deep), padded to RR_PF
+    int ring[RR_PF][NVS];
 #pragma unroll
-      for (int s = 0; s < NVS; ++s) e[s] = en[s];
-      if (r + 1 < nrows) {
-        lvn = T.solve_bwd_level[r + 1];
+    for (int u = 0; u < RR_PF; ++u)
 #pragma unroll
-        for (int s = 0; s < NVS; ++s) en[s] = T.solve_bwd[(r + 1) * W + s * RR_LANES + lane];
-      }
-      if (lv >= 0) {   // dofs of depth lv are final: publish them
+      for (int s = 0; s < NVS; ++s) ring[u][s] = T.solve_seq[u * W2 + s * RR_LANES + lane];
+    sync();
+    const int nrow = 2 * D.dmax;
+    for (int r0 = 0; r0 < nrow; r0 += RR_PF) {
 #pragma unroll
-        for (int s = 0; s < NVS; ++s) {
-          const int d = lane + RR_LANES * s;
-          if (d < D.nv && dofdepth[s] == lv) s_x[d] = x[s];
+      for (int u = 0; u < RR_PF; ++u) {
+        const int r = r0 + u;
+        int e[NVS];
+#pragma unroll
+        for (int s = 0; s < NVS; ++s) e[s] = ring[u][s];
+        if (r0 + RR_PF < nrow) {
+#pragma unroll
+          for (int s = 0; s < NVS; ++s) ring[u][s] = T.solve_seq[(r + RR_PF) * W2 + s * RR_LANES + lane];
         }
-        sync();
-      }
+        if (r == D.dmax) {   // between the passes: x <- D^-1 x
 #pragma unroll
-      for (int s = 0; s < NVS; ++s)
-        if (e[s] >= 0) x[s] -= s_qLD[e[s] >> 8] * s_x[e[s] & 255];
+          for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; if (d < D.nv) s_x[d] *= dinv[s]; }
+          sync();
+        }
+        if (r < nrow) {
+          if (r < D.dmax) {
+#pragma unroll
+            for (int s = 0; s < NVS; ++s)
+              if (e[s] >= 0) atomicAdd(s_x + (e[s] >> 20), -(s_qLD[e[s] & 4095] * s_x[(e[s] >> 12) & 255]));
+          } else {
+#pragma unroll
+            for (int s = 0; s < NVS; ++s)
+              if (e[s] >= 0) atomicAdd(s_x + ((e[s] >> 12) & 255), -(s_qLD[e[s] & 4095] * s_x[e[s] >> 20]));
+          }
+          sync();
+        }
+      }
     }
 #pragma unroll
-    for (int s = 0; s < NVS; ++s) { x[s] *= dinv[s]; en[s] = T.solve_fwd[s * RR_LANES + lane]; }
-    for (int l = 0; l < D.dmax; ++l) {
-      int e[NVS];
-#pragma unroll
-      for (int s = 0; s < NVS; ++s) e[s] = en[s];
-      if (l + 1 < D.dmax) {
-#pragma unroll
-        for (int s = 0; s < NVS; ++s) en[s] = T.solve_fwd[(l + 1) * W + s * RR_LANES + lane];
-      }
-#pragma unroll
-      for (int s = 0; s < NVS; ++s) {
-        const int d = lane + RR_LANES * s;
-        if (d < D.nv && dofdepth[s] == l) s_x[d] = x[s];
-      }
-      sync();
-#pragma unroll
-      for (int s = 0; s < NVS; ++s)
-        if (e[s] >= 0) x[s] -= s_qLD[e[s] >> 8] * s_x[e[s] & 255];
-    }
+    for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; x[s] = d < D.nv ? s_x[d] : 0.0f; }
     sync();  // s_x may be rewritten by the next call
   }
 
-  // y = M * s_vec   (s_vec must be visible); table rows in batches of RR_U
+  // y = M * s_vec (s_vec must be visible).  Entry-parallel: lane owns matrix entries e = lane + 64 it (row/col ids
+  // in registers) and adds M_ij x_j to y_i and M_ij x_i to y_j with LDS float atomics: perfectly balanced, no tables.
   __device__ __forceinline__ void mul_m(float* y) {
 #pragma unroll
-    for (int s = 0; s < NVS; ++s) y[s] = 0.0f;
-    for (int t0 = 0; t0 < D.T_mulm; t0 += RR_U) {
-      int e[RR_U][NVS];
+    for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; if (d < D.nv) s_y[d] = 0.0f; }
+    sync();
 #pragma unroll
-      for (int u = 0; u < RR_U; ++u)
-#pragma unroll
-        for (int s = 0; s < NVS; ++s) e[u][s] = T.mulm[(t0 + u) * W + s * RR_LANES + lane];
-#pragma unroll
-      for (int u = 0; u < RR_U; ++u)
-#pragma unroll
-        for (int s = 0; s < NVS; ++s)
-          if (e[u][s] >= 0) y[s] += s_qM[e[u][s] >> 8] * s_vec[e[u][s] & 255];
+    for (int it = 0; it < NME; ++it) {
+      const int ij = ment[it];
+      if (ij >= 0) {
+        const int i = ij & 255, j = ij >> 8;
+        const float mij = s_qM[lane + RR_LANES * it];
+        atomicAdd(s_y + i, mij * s_vec[j]);
+        if (i != j) atomicAdd(s_y + j, mij * s_vec[i]);
+      }
     }
+    sync();
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; y[s] = d < D.nv ? s_y[d] : 0.0f; }
+    sync();
   }
 
   __device__ __forceinline__ void put_vec(const float* x) {
@@ -576,7 +694,7 @@ struct Wave {
         const float qv = s_qvel[d];
         float passive = -df[1] * qv;
         if (di[2] == 6) passive -= df[2] * (s_qpos[di[6]] - df[3]);
-        const float bias = dot6(s_cdof + 6 * d, s_cfrc + 6 * di[0]);
+        const float bias = dot6(s_cdof + 6 * d, s_cfrc + 6 * dofbody[s]);
         float actf = 0.0f;
         const int u = di[7];
         if (u >= 0) {
@@ -685,20 +803,21 @@ struct Wave {
           con_jadr[cs] = jadr; con_nanc[cs] = nanc;
           const v3 off = pos - get_com(r);
           float jnv = 0, j1v = 0, j2v = 0;
-          for (int p0 = 0; p0 < nanc; p0 += RR_U) {
-            int ddv[RR_U];
 #pragma unroll
-            for (int u = 0; u < RR_U; ++u) ddv[u] = T.con_chain[(p0 + u) * WC + c];
+          for (int p0 = 0; p0 < 36; p0 += 4) {
+            if (__any(p0 < nanc)) {
 #pragma unroll
-            for (int u = 0; u < RR_U; ++u) {
-              const int dd = ddv[u], p = p0 + u;
-              if (dd >= 0) {
-                const float* cd = s_cdof + 6 * dd;
-                const v3 jp = ld3(cd + 3) + cross(ld3(cd), off);
-                const float jn = dot(n, jp), j1 = dot(fb, jp), j2 = dot(fc, jp);
-                s_J[jadr + 3 * p] = jn; s_J[jadr + 3 * p + 1] = j1; s_J[jadr + 3 * p + 2] = j2;
-                const float qv = s_qvel[dd];
-                jnv += jn * qv; j1v += j1 * qv; j2v += j2 * qv;
+              for (int u = 0; u < 4; ++u) {
+                const int p = p0 + u;
+                if (p < nanc) {
+                  const int dd = chain_at(cs, p);
+                  const float* cd = s_cdof + 6 * dd;
+                  const v3 jp = ld3(cd + 3) + cross(ld3(cd), off);
+                  const float jn = dot(n, jp), j1 = dot(fb, jp), j2 = dot(fc, jp);
+                  s_J[jadr + 3 * p] = jn; s_J[jadr + 3 * p + 1] = j1; s_J[jadr + 3 * p + 2] = j2;
+                  const float qv = s_qvel[dd];
+                  jnv += jn * qv; j1v += j1 * qv; j2v += j2 * qv;
+                }
               }
             }
           }
@@ -724,19 +843,19 @@ struct Wave {
     for (int cs = 0; cs < NCS; ++cs) {
       out[cs][0] = out[cs][1] = out[cs][2] = out[cs][3] = 0.0f;
       if (con_act[cs]) {
-        const int c = lane + RR_LANES * cs;
         float jn = 0, j1 = 0, j2 = 0;
         const int jadr = con_jadr[cs];
-        for (int p0 = 0; p0 < con_nanc[cs]; p0 += RR_U) {
-          int ddv[RR_U];
+        const int nanc = con_nanc[cs];
 #pragma unroll
-          for (int u = 0; u < RR_U; ++u) ddv[u] = T.con_chain[(p0 + u) * WC + c];
+        for (int p0 = 0; p0 < 36; p0 += 4) {
+          if (__any(p0 < nanc)) {
 #pragma unroll
-          for (int u = 0; u < RR_U; ++u) {
-            if (ddv[u] >= 0) {
-              const float xv = s_vec[ddv[u]];
+            for (int u = 0; u < 4; ++u) {
               const int p = p0 + u;
-              jn += s_J[jadr + 3 * p] * xv; j1 += s_J[jadr + 3 * p + 1] * xv; j2 += s_J[jadr + 3 * p + 2] * xv;
+              if (p < nanc) {
+                const float xv = s_vec[chain_at(cs, p)];
+                jn += s_J[jadr + 3 * p] * xv; j1 += s_J[jadr + 3 * p + 1] * xv; j2 += s_J[jadr + 3 * p + 2] * xv;
+              }
             }
           }
         }
@@ -750,52 +869,49 @@ struct Wave {
   __device__ __forceinline__ void update_constraint() {
     float part[2] = {0.0f, 0.0f};  // [0] = sum D*Jaref^2 over active rows, [1] = gauss dot
 #pragma unroll
-    for (int cs = 0; cs < NCS; ++cs) {
-      const int c = lane + RR_LANES * cs;
-      if (c < D.ncon) {
-        float f[4] = {0, 0, 0, 0};
-        if (con_act[cs]) {
+    for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; if (d < D.nv) s_y[d] = 0.0f; }
+    sync();
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float jr = con_jar[cs][k];
-            if (jr < 0) { f[k] = -con_D[cs] * jr; part[0] += con_D[cs] * jr * jr; }
-          }
+    for (int cs = 0; cs < NCS; ++cs) {
+      if (con_act[cs]) {
+        float f[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float jr = con_jar[cs][k];
+          if (jr < 0) { f[k] = -con_D[cs] * jr; part[0] += con_D[cs] * jr * jr; }
         }
         const float mu = con_mu[cs];
-        s_cf[3 * c] = f[0] + f[1] + f[2] + f[3];
-        s_cf[3 * c + 1] = mu * (f[0] - f[1]);
-        s_cf[3 * c + 2] = mu * (f[2] - f[3]);
+        const float fn = f[0] + f[1] + f[2] + f[3], f1 = mu * (f[0] - f[1]), f2 = mu * (f[2] - f[3]);
+        if (fn != 0.0f) {   // J' f of this contact scattered along its ancestor chain (LDS float atomics)
+          const int jadr = con_jadr[cs], nanc = con_nanc[cs];
+#pragma unroll
+          for (int p0 = 0; p0 < 36; p0 += 4) {
+            if (__any(p0 < nanc)) {
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const int p = p0 + u;
+                if (p < nanc)
+                  atomicAdd(s_y + chain_at(cs, p), s_J[jadr + 3 * p] * fn + s_J[jadr + 3 * p + 1] * f1 + s_J[jadr + 3 * p + 2] * f2);
+              }
+            }
+          }
+        }
       }
     }
+    sync();
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
-      qfrc_con[s] = 0.0f;
+      const int d = lane + RR_LANES * s;
+      float qc = d < D.nv ? s_y[d] : 0.0f;
       if (lim_act[s] && lim_jar[s] < 0) {
         const float f = -lim_D[s] * lim_jar[s];
         part[0] += lim_D[s] * lim_jar[s] * lim_jar[s];
-        qfrc_con[s] = lim_sign[s] * f;
+        qc += lim_sign[s] * f;
       }
+      qfrc_con[s] = qc;
       part[1] += (Ma[s] - qfrc_smooth[s]) * (qacc[s] - qacc_smooth[s]);
     }
     sync();
-    for (int t0 = 0; t0 < D.T_jtf; t0 += RR_U) {
-      int ev[RR_U][NVS];
-#pragma unroll
-      for (int u = 0; u < RR_U; ++u)
-#pragma unroll
-        for (int s = 0; s < NVS; ++s) ev[u][s] = T.jtf[(t0 + u) * W + s * RR_LANES + lane];
-#pragma unroll
-      for (int u = 0; u < RR_U; ++u)
-#pragma unroll
-        for (int s = 0; s < NVS; ++s) {
-          const int e = ev[u][s];
-          if (e >= 0) {
-            const int c = e & 255, adr = e >> 8;
-            if (con_bit(c))
-              qfrc_con[s] += s_J[adr] * s_cf[3 * c] + s_J[adr + 1] * s_cf[3 * c + 1] + s_J[adr + 2] * s_cf[3 * c + 2];
-          }
-        }
-    }
     wave_sum_n<2>(part);
     gauss = 0.5f * part[1];
     prev_cost = cost;
@@ -925,6 +1041,7 @@ struct Wave {
   }
 
   // [UP mjx solver.solve] primal CG with warm start; returns the iteration count
+  template <bool PROF>
   __device__ __forceinline__ int solve() {
     const float scale = 1.0f / (D.meaninertia * (float)(D.nv > 1 ? D.nv : 1));
 #pragma unroll
@@ -939,6 +1056,7 @@ struct Wave {
       for (int s = 0; s < NVS; ++s) qacc[s] = qacc_smooth[s];
     }
     ctx_create(true);
+    stamp<PROF>(8);
     int niter = 0;
     while (true) {
       const float improvement = (prev_cost - cost) * scale;
@@ -950,12 +1068,16 @@ struct Wave {
       done |= improvement < D.tolerance;
       done |= gradient < D.tolerance;
       if (uni(done)) break;
+      stamp<PROF>(12);
       linesearch();
+      stamp<PROF>(9);
       float pm[NVS], gg = 0.0f;
 #pragma unroll
       for (int s = 0; s < NVS; ++s) { gg += grad[s] * Mgrad[s]; pm[s] = Mgrad[s]; }
       update_constraint();
+      stamp<PROF>(10);
       update_gradient();
+      stamp<PROF>(11);
       float bt[2] = {0.0f, gg};
 #pragma unroll
       for (int s = 0; s < NVS; ++s) bt[0] += grad[s] * (Mgrad[s] - pm[s]);
@@ -1013,7 +1135,7 @@ struct Wave {
 };
 
 // ------------------------------------------------------------------------------------------ kernel
-template <int NBS, int NVS, int NCS>
+template <int NBS, int NVS, int NCS, bool PROF>
 __global__ __launch_bounds__(RR_LANES) void rr_step_kernel(const RRDims D, const RRTables T, const RRIO io, const int num_envs,
                                                            const int n_frames) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1037,8 +1159,36 @@ __global__ __launch_bounds__(RR_LANES) void rr_step_kernel(const RRDims D, const
     w.dofdepth[s] = d < D.nv ? T.dof_i[RR_DOFI * d + 3] : -1;
     w.dofmadr[s] = d < D.nv ? T.dof_i[RR_DOFI * d + 4] : 0;
     w.doflast[s] = d < D.nv ? T.dof_i[RR_DOFI * d + 10] : -1;
+    w.dofbody[s] = d < D.nv ? T.dof_i[RR_DOFI * d] : 0;
+    w.dofkind[s] = d < D.nv ? T.dof_i[RR_DOFI * d + 2] : 6;
+    w.dofroot[s] = d < D.nv ? T.dof_i[RR_DOFI * d + 9] : 0;
+    w.dofqadr[s] = d < D.nv ? T.dof_i[RR_DOFI * d + 6] : 0;
+    w.dofq0[s] = (d < D.nv && w.dofkind[s] == 6) ? T.jnt_f[8 * T.dof_i[RR_DOFI * d + 1] + 6] : 0.0f;
     w.qacc[s] = w.Ma[s] = w.grad[s] = w.Mgrad[s] = w.search[s] = w.mv[s] = w.qfrc_con[s] = 0.0f;
   }
+  // ---- model constants -> registers (once per launch)
+  w.bc0 = load_bodyc(T, lane, D.nbody);
+#pragma unroll
+  for (int s = 0; s < NBS; ++s) {
+    const int b = lane + RR_LANES * s;
+    const bool ok = b >= 1 && b < D.nbody;
+    w.bdepth[s] = ok ? T.body_i[RR_BODYI * b + 8] : -1;
+    w.bsib[s] = ok ? T.body_i[RR_BODYI * b + 9] : 0;
+  }
+#pragma unroll
+  for (int it = 0; it < Wave<NBS, NVS, NCS>::NME; ++it) {
+    const int e = lane + RR_LANES * it;
+    int v = -1;
+    if (e < D.nM) { const int ij = T.M_ij[e]; v = (ij & 0xffff) | ((ij >> 16) << 8); }
+    w.ment[it] = v;
+  }
+  w.bwd_step_r[0] = lane < D.nbwd ? T.bwd_steps[lane] : 0;
+  w.bwd_step_r[1] = lane + RR_LANES < D.nbwd ? T.bwd_steps[lane + RR_LANES] : 0;
+#pragma unroll
+  for (int cs = 0; cs < NCS; ++cs)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w.con_chain[cs][k] = T.con_chain_packed[k * (NCS * RR_LANES) + cs * RR_LANES + lane];
+  for (int i = lane; i < D.nv; i += RR_LANES) w.s_arm[i] = T.dof_f[16 * i];
 #pragma unroll
   for (int i = 0; i < Wave<NBS, NVS, NCS>::RR_TRI; ++i) { const int t = lane + RR_LANES * i; w.tri_r[i] = t < D.ntri ? T.tri[t] : 0; }
   if (lane == 0) {  // world body
@@ -1052,21 +1202,30 @@ __global__ __launch_bounds__(RR_LANES) void rr_step_kernel(const RRDims D, const
   }
   w.sync();
 
+  if (PROF) { for (int i = 0; i < RR_NPH; ++i) w.pt[i] = 0; w.pt_last = __builtin_readcyclecounter(); }
   const int frames = (io.mode & 1) ? n_frames : 1;
   int niter = 0;
   for (int f = 0; f < frames; ++f) {
     float* dg = (f == frames - 1) ? dbg : nullptr;
     float bias[NVS], passive[NVS];
+    w.template stamp<PROF>(15);
     w.kinematics();
+    w.template stamp<PROF>(0);
     w.com_pos();
+    w.template stamp<PROF>(1);
     w.velocity_sweep();
+    w.template stamp<PROF>(2);
     w.backward_sweep();
+    w.template stamp<PROF>(3);
     w.mass_matrix();
+    w.template stamp<PROF>(4);
     w.factor(0.0f);
+    w.template stamp<PROF>(5);
     w.smooth_forces(bias, passive);
 #pragma unroll
     for (int s = 0; s < NVS; ++s) w.qacc_smooth[s] = w.qfrc_smooth[s];
     w.ldl_solve(w.qacc_smooth);
+    w.template stamp<PROF>(6);
     if (dg) {  // dump before the solver / integrator reuse buffers
       for (int e = lane; e < 3 * D.nbody; e += RR_LANES) dg[D.g_xpos + e] = w.s_xpos[e];
       for (int e = lane; e < 4 * D.nbody; e += RR_LANES) dg[D.g_xquat + e] = w.s_xquat[e];
@@ -1087,7 +1246,9 @@ __global__ __launch_bounds__(RR_LANES) void rr_step_kernel(const RRDims D, const
       }
     }
     w.constraints(dg);
-    niter = w.solve();
+    w.template stamp<PROF>(7);
+    niter = w.template solve<PROF>();
+    w.template stamp<PROF>(12);
     if (dg) {
 #pragma unroll
       for (int s = 0; s < NVS; ++s) {
@@ -1098,8 +1259,11 @@ __global__ __launch_bounds__(RR_LANES) void rr_step_kernel(const RRDims D, const
       if (lane == 0) { dg[D.g_misc] = (float)niter; dg[D.g_misc + 1] = w.cost; }
     }
     if (io.mode & 1) w.euler();
+    w.template stamp<PROF>(13);
   }
 
+  w.template stamp<PROF>(14);
+  if (PROF && io.prof && lane == 0) for (int i = 0; i < RR_NPH; ++i) io.prof[(size_t)env * RR_NPH + i] = w.pt[i];
   // ---- write back state
   for (int i = lane; i < D.nq; i += RR_LANES) io.qpos[(size_t)env * D.nq + i] = w.s_qpos[i];
   for (int i = lane; i < D.nv; i += RR_LANES) io.qvel[(size_t)env * D.nv + i] = w.s_qvel[i];

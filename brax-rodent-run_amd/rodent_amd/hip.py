@@ -39,7 +39,7 @@ class RREnvIO(C.Structure):
 
 EXPORTS = ["rr_model_load", "rr_model_dims", "rr_model_set_solver", "rr_model_destroy", "rr_batch_create",
            "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset",
-           "rr_debug_layout", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
+           "rr_debug_layout", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
 
 _lib = None
 
@@ -67,6 +67,7 @@ def lib():
         L.rr_env_reset.argtypes = [C.c_void_p, C.POINTER(RRState), C.POINTER(RREnvIO), C.POINTER(RROutputs)]
         L.rr_debug_layout.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_int32)),
                                       C.POINTER(C.POINTER(C.c_int32))]
+        L.rr_batch_set_profile.argtypes = [C.c_void_p, C.c_void_p]
         L.rr_batch_set_timing.argtypes = [C.c_void_p, C.c_int32]
         L.rr_batch_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         _lib = L
@@ -197,6 +198,10 @@ class Batch:
         names, offs, sizes = C.POINTER(C.c_char_p)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
         n = _check(lib().rr_debug_layout(self.h, C.byref(names), C.byref(offs), C.byref(sizes)))
         return {names[i].decode(): (offs[i], sizes[i]) for i in range(n)}
+
+    def set_profile(self, buf: Optional[torch.Tensor]):
+        """Diagnostic: int64 device tensor [N,16] receiving per-phase cycle sums (None = off)."""
+        _check(lib().rr_batch_set_profile(self.h, buf.data_ptr() if buf is not None else None))
 
     def set_timing(self, enable: bool):
         _check(lib().rr_batch_set_timing(self.h, int(enable)))

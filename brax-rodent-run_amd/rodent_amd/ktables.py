@@ -60,8 +60,22 @@ def build_kernel_tables(m):
     k["k_body_root"] = np.asarray([root_index.get(int(r), 0) for r in m["body_rootid"]], np.int32)
 
     # ---- packed per-body / per-joint / per-dof parameter rows
+    sib = np.zeros(nb, np.int32)                      # rank among siblings, largest body id first: the
+    for b in range(nb):                               # backward sweeps add children into the parent in that
+        kids = [c for c in range(1, nb) if par[c] == b]   # order (= the reference's `for b = nb-1..1` loop)
+        for r, c in enumerate(sorted(kids, reverse=True)):
+            sib[c] = r
+    if int(m["body_jntnum"].max()) > 3:
+        raise ValueError("more than 3 joints on one body is not supported by the kernel")
     k["k_body_i"] = np.stack([par, m["body_jntadr"], m["body_jntnum"], m["body_dofadr"], m["body_dofnum"],
-                              k["k_body_root"], child_adr[:-1], child_adr[1:] - child_adr[:-1]], axis=1).astype(np.int32)
+                              k["k_body_root"], child_adr[:-1], child_adr[1:] - child_adr[:-1], depth, sib,
+                              np.zeros(nb, np.int32), np.zeros(nb, np.int32)], axis=1).astype(np.int32)   # 12 ints
+    # backward-sweep schedule: (level, sibling rank) steps, deepest level first; level 1 bodies hang off the world
+    steps = []
+    for L in range(nlevel, 1, -1):
+        for r in range(int(max(sib[b] for b in range(1, nb) if depth[b] == L)) + 1):
+            steps.append(L | (r << 8))
+    k["k_bwd_steps"] = np.asarray(steps if steps else [0], np.int32)
     k["k_body_f"] = np.concatenate([m["body_pos"], m["body_quat"], m["body_ipos"], m["body_iquat"],
                                     m["body_mass"][:, None], m["body_inertia"]], axis=1)  # 18 floats
     qa = m["jnt_qposadr"]
@@ -184,6 +198,53 @@ def build_kernel_tables(m):
     k["k_solve_bwd_adr"] = np.asarray(bwd_adr, np.int32)     # entry i: first row of level dmax-i
     k["k_solve_bwd_level"] = np.asarray(bwd_level if bwd_level else [-1], np.int32)  # level published before row r, or -1
 
+    # ---- level-parallel solve / factor schedules (entries of ALL dofs of one depth level side by side on the lanes;
+    #      the kernel combines them with LDS float atomics, so a level is one step instead of one per dof / descendant)
+    by_level = [[i for i in range(nv) if ddepth[i] == l] for l in range(dmax + 1)]
+    np2 = max(1, max((len(by_level[l]) * l + LANES - 1) // LANES for l in range(dmax + 1)))
+    W2 = np2 * LANES
+
+    def level_entries(l):
+        out = []
+        for i in by_level[l]:
+            chain = anc[anc_adr[i]:anc_adr[i + 1]][::-1]          # self, parent, ..., root
+            for p in range(1, l + 1):
+                out.append((Madr[i] + p) | (i << 12) | (int(chain[p]) << 20))
+        return out
+
+    if nM >= 4096:
+        raise ValueError("nM above the 12-bit address field of the solve tables")
+    sol = np.full((max(1, dmax), W2), -1, np.int32)
+    for l in range(1, dmax + 1):
+        ent = level_entries(l)
+        sol[l - 1, :len(ent)] = ent
+    PF = 4                                                     # rows the kernel keeps in flight (RR_PF)
+    seq = np.concatenate([sol[::-1], sol], axis=0)              # backward pass rows (deep -> shallow), then forward rows
+    pad = (-seq.shape[0]) % PF + PF
+    k["k_solve_seq"] = np.concatenate([seq, np.full((pad, W2), -1, np.int32)], axis=0)
+    k["k_solve2"] = sol                                        # row l-1: entries (e | i<<12 | j<<20) with depth(i) = l
+    frows, flevel = [], []
+    for l in range(dmax, 0, -1):
+        upd = []
+        for kk in by_level[l]:
+            chain = anc[anc_adr[kk]:anc_adr[kk + 1]][::-1]
+            for q in range(1, l + 1):
+                for p in range(1, q + 1):
+                    dst = Madr[int(chain[p])] + (q - p)
+                    upd.append(((Madr[kk] + p) | ((Madr[kk] + q) << 12), dst | (Madr[kk] << 12)))
+        for r0 in range(0, len(upd), LANES):
+            row = np.full((LANES, 2), -1, np.int32)
+            blk = upd[r0:r0 + LANES]
+            row[:len(blk)] = blk
+            frows.append(row)
+            flevel.append(1 if r0 == 0 else 0)
+    while len(frows) % PF or not frows:                          # pad to a multiple of the prefetch ring
+        frows.append(np.full((LANES, 2), -1, np.int32)); flevel.append(0)
+    frows += [np.full((LANES, 2), -1, np.int32)] * PF; flevel += [0] * PF   # slack rows the ring may prefetch
+    k["k_factor2"] = np.stack(frows).astype(np.int32)            # [R + PF][64][2]
+    k["k_factor2_first"] = np.asarray(flevel, np.int32)          # row opens a new level
+    k["k_factor2_rows"] = np.int32(len(frows) - PF)
+
     # ---- contacts
     WC = NCS * LANES
     g2 = m["con_geom2"]
@@ -215,5 +276,12 @@ def build_kernel_tables(m):
             chain_tab[p, c] = int(dd)
             rows[int(dd)].append(c | ((m["con_jadr"][c] + 3 * p) << 8))
     k["k_con_chain"] = chain_tab
+    if maxc > 36:
+        raise ValueError("contact ancestor chains longer than 36 dofs are not supported by the kernel")
+    packed = np.zeros((9, WC), np.int64)
+    for c in range(ncon):
+        for p in range(int(nanc[c])):
+            packed[p // 4, c] |= int(chain_tab[p, c]) << (8 * (p % 4))
+    k["k_con_chain_packed"] = packed.astype(np.uint32).view(np.int32)
     k["k_jtf"] = lane_table(rows)
     return k

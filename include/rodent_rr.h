@@ -114,6 +114,10 @@ int rr_debug_layout(const rr_batch* b, const char*** names, const int32_t** offs
 int rr_batch_set_timing(rr_batch* b, int32_t enable);
 int rr_batch_kernel_time(rr_batch* b, double* total_ms, int64_t* launches);
 
+/* Diagnostic only (never in a timed run): route launches to the s_memtime-instrumented build of the kernel, which
+ * writes per-phase cycle sums of each env into dev_cycles [N][16] (uint64, device).  NULL switches back. */
+int rr_batch_set_profile(rr_batch* b, uint64_t* dev_cycles);
+
 const char* rr_last_error(void);
 
 #ifdef __cplusplus

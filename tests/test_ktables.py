@@ -151,3 +151,62 @@ def test_level_tables(model_and_state):
             assert m["body_parentid"][b] == 0 or m["body_parentid"][b] in seen
         seen.update(int(b) for b in bodies)
     assert seen == set(range(1, M.nbody))
+
+
+def kernel_factor2(m, qM):
+    """numpy restatement of the level-parallel Wave::factor (k_factor2 rows, atomics = np.add.at)."""
+    L = qM.copy()
+    tab, first = m["k_factor2"], m["k_factor2_first"]
+    for r in range(tab.shape[0]):
+        e = tab[r]
+        ok = e[:, 0] >= 0
+        a, bq = e[ok, 0] & 4095, e[ok, 0] >> 12
+        dst, piv = e[ok, 1] & 4095, e[ok, 1] >> 12
+        np.add.at(L, dst, -(L[bq] * (L[a] / L[piv])))
+    Madr = m["k_dof_i"][:, 4]
+    dinv = 1.0 / L[Madr]
+    for e_, ij in enumerate(m["k_M_ij"]):
+        i, j = ij & 0xFFFF, ij >> 16
+        if i != j:
+            L[e_] *= dinv[i]
+    return L, dinv
+
+
+def kernel_solve2(m, L, dinv, x):
+    """numpy restatement of the level-parallel Wave::ldl_solve (k_solve2 rows)."""
+    nv = int(m["nv"])
+    tab = m["k_solve2"]
+    sx = x.copy()
+    for l in range(tab.shape[0] - 1, -1, -1):
+        e = tab[l][tab[l] >= 0]
+        np.add.at(sx, e >> 20, -(L[e & 4095] * sx[(e >> 12) & 255]))
+    sx *= dinv
+    for l in range(tab.shape[0]):
+        e = tab[l][tab[l] >= 0]
+        np.add.at(sx, (e >> 12) & 255, -(L[e & 4095] * sx[e >> 20]))
+    return sx
+
+
+def test_level_parallel_factor_and_solve_tables(model_and_state):
+    m, M, d = model_and_state
+    qM, qLD = d.get("qM"), d.get("qLD")
+    L, dinv = kernel_factor2(m, qM)
+    np.testing.assert_allclose(L, qLD, rtol=1e-9, atol=1e-16)
+    np.testing.assert_allclose(dinv, d.get("qLDiagInv"), rtol=1e-9)
+    Md = dense_from_sparse(m, qM)
+    b = np.random.default_rng(4).normal(size=M.nv)
+    x = kernel_solve2(m, L, dinv, b)
+    np.testing.assert_allclose(Md @ x, b, rtol=1e-7, atol=1e-9)
+    # a level's rows never read an entry that the same level writes (reads: rows of that level; writes: ancestor rows)
+    tab, first = m["k_factor2"], m["k_factor2_first"]
+    r = 0
+    while r < tab.shape[0]:
+        r1 = r + 1
+        while r1 < tab.shape[0] and not first[r1]:
+            r1 += 1
+        e = tab[r:r1].reshape(-1, 2)
+        e = e[e[:, 0] >= 0]
+        reads = set((e[:, 0] & 4095).tolist()) | set((e[:, 0] >> 12).tolist()) | set((e[:, 1] >> 12).tolist())
+        writes = set((e[:, 1] & 4095).tolist())
+        assert not (reads & writes)
+        r = r1
