@@ -44,13 +44,15 @@ static void layout(rr_model* m) {
   int o = 0;
   auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
   k.o_qpos = take(d.nq); k.o_qvel = take(d.nv); k.o_act = take(d.nu); k.o_ctrl = take(d.nu);
-  k.o_xpos = take(3 * d.nbody); k.o_xquat = take(4 * d.nbody); k.o_xmat = take(9 * d.nbody);
-  k.o_cinert = take(10 * d.nbody); k.o_crb = take(10 * d.nbody); k.o_cdof = take(6 * d.nv);
-  k.o_cvel = take(6 * d.nbody); k.o_cacc = take(6 * d.nbody); k.o_cfrc = take(6 * d.nbody); k.o_buf = take(6 * d.nv);
-  k.o_qM = take(d.nM); k.o_qLD = take(d.nM);
+  // pose cells (xpos | xquat) are recycled as the 6*nv scratch of the mass-matrix build
+  { const int pose = std::max(7 * d.nbody + 4, 6 * d.nv); k.o_xpos = take(pose); k.o_xquat = k.o_xpos + ((3 * d.nbody + 3) & ~3); }
+  k.o_cinert = take(10 * d.nbody);   // composite inertia accumulates in place
+  k.o_cdof = take(6 * d.nv); k.o_cvel = take(6 * d.nbody);
+  k.o_qM = take(d.nM);
+  k.o_qLD = take(std::max(std::max(d.nM, 12 * d.nbody), 2 * d.nv));   // also cacc | cfrc and the sin/cos scratch
   const int32_t* jadr = (const int32_t*)m->find("con_jadr")->data;
   k.nJ = jadr[d.ncon];
-  k.o_J = take(jadr[d.ncon]); k.o_cf = take(3 * d.ncon); k.o_vec = take(d.nv); k.o_x = take(d.nv); k.o_y = take(d.nv); k.o_arm = take(2 * d.nv);
+  k.o_vec = take(d.nv); k.o_x = take(d.nv); k.o_y = take(d.nv); k.o_arm = take(2 * d.nv);
   k.lds_floats = o;
   // debug dump
   int g = 0;
@@ -64,7 +66,6 @@ static void layout(rr_model* m) {
   k.g_con_dist = dbg("con_dist", d.ncon); k.g_con_pos = dbg("con_pos", 3 * d.ncon); k.g_con_frame = dbg("con_frame", 9 * d.ncon);
   k.g_con_D = dbg("con_D", d.ncon); k.g_con_aref = dbg("con_aref", 4 * d.ncon); k.g_lim = dbg("limit_pos_D_aref", 3 * d.nv);
   k.g_qacc = dbg("qacc", d.nv); k.g_qfrc_constraint = dbg("qfrc_constraint", d.nv); k.g_misc = dbg("niter_cost", 2);
-  k.g_J = dbg("J", jadr[d.ncon]);
   k.dbg_floats = g;
   for (auto& s : m->dbg_names) m->dbg_cnames.push_back(s.c_str());
   m->dims.lds_bytes = o * (int)sizeof(float);
@@ -215,7 +216,7 @@ extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t devi
   UP(act_f, "k_act_f") UP(con_f, "k_con_f") UP(root_mass, "k_root_mass")
 #undef UP
   kern_t kern = pick_kernel(m->NBS, m->NVS, m->NCS);
-  if (m->dims.lds_bytes > 160 * 1024) { rr_batch_destroy(b); return fail(RR_EUNSUPPORTED, "rr_batch_create: per-env working set exceeds 160 KiB LDS"); }
+  if (m->dims.lds_bytes > 64 * 1024) { rr_batch_destroy(b); return fail(RR_EUNSUPPORTED, "rr_batch_create: per-env working set exceeds 160 KiB LDS"); }
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, m->dims.lds_bytes);
   if (e != hipSuccess) { rr_batch_destroy(b); return fail(RR_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
   *out = b;

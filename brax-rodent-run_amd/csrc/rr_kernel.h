@@ -31,8 +31,8 @@ struct RRDims {
   int T_mulm, T_jtf, T_chain, obs_dim, iterations, ls_iterations, nJ, ntri, nbwd, nfac;
   float dt, gx, gy, gz, tolerance, ls_tolerance, meaninertia;
   // LDS offsets (floats)
-  int o_qpos, o_qvel, o_act, o_ctrl, o_xpos, o_xquat, o_xmat, o_cinert, o_crb, o_cdof, o_cvel, o_cacc, o_cfrc, o_buf,
-      o_qM, o_qLD, o_J, o_cf, o_vec, o_x, o_y, o_arm, lds_floats;
+  int o_qpos, o_qvel, o_act, o_ctrl, o_xpos, o_xquat, o_cinert, o_cdof, o_cvel,
+      o_qM, o_qLD, o_vec, o_x, o_y, o_arm, lds_floats;
   // debug dump offsets (floats)
   int g_xpos, g_xquat, g_xmat, g_com, g_cinert, g_crb, g_cdof, g_cvel, g_cfrc, g_qM, g_qLD, g_dinv, g_bias, g_passive,
       g_actuator, g_smooth, g_qacc_smooth, g_con_dist, g_con_pos, g_con_frame, g_con_D, g_con_aref, g_lim, g_qacc,
@@ -184,37 +184,35 @@ __device__ __forceinline__ void kbi(float dt, float sr0, float sr1, const float*
 
 struct LSPoint { float alpha, cost, d0, d1; };
 
-// Per-body model constants.  Slot 0 (bodies 0..63) lives in registers for the whole launch; bodies >= 64
-// (a handful at most) reload theirs from the L2-resident tables at the tree levels where they are active.
+// Identity the optimiser cannot see through: stops loop-invariant code motion from unpacking every packed index
+// table entry once, ahead of the solver loops, and keeping hundreds of unpacked indices / addresses alive in
+// registers (the unpack is 2 VALU ops; the registers are what limits residency).
+__device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+
+// Per-body model constants of the tree sweeps.  For bodies 0..63 (slot 0) they live in registers for the whole
+// launch; a body's 2nd/3rd joint (a dozen bodies have one) and bodies >= 64 reload from the L2-resident tables.
 struct BodyC {
-  int parent, depth, sib, root, dofadr, dofnum, jn;
-  int jtype[3], jqa[3], jda[3];
-  float pos[3], quat[4], ipos[3], iquat[4], mass, inertia[3];
-  float jpos[3][3], jaxis[3][3], jq0[3];
+  int parent, depth, sib, dofadr, dofnum, jn, jadr;
+  int jtype0, jqa0, jda0;
+  float pos[3], quat[4], jpos0[3], jaxis0[3];
 };
 __device__ __forceinline__ BodyC load_bodyc(const RRTables& T, int b, int nbody) {
   BodyC c;
   const bool ok = b >= 1 && b < nbody;
   const int* bi = T.body_i + RR_BODYI * (ok ? b : 0);
   const float* bf = T.body_f + 18 * (ok ? b : 0);
-  c.parent = bi[0]; c.dofadr = bi[3]; c.dofnum = bi[4]; c.root = bi[5];
-  c.depth = ok ? bi[8] : -1; c.sib = bi[9]; c.jn = ok ? bi[2] : 0;
+  c.parent = bi[0]; c.jadr = bi[1]; c.jn = ok ? bi[2] : 0; c.dofadr = bi[3]; c.dofnum = bi[4];
+  c.depth = ok ? bi[8] : -1; c.sib = bi[9];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) { c.pos[k] = bf[k]; c.ipos[k] = bf[7 + k]; c.inertia[k] = bf[15 + k]; }
+  for (int k = 0; k < 3; ++k) c.pos[k] = bf[k];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { c.quat[k] = bf[3 + k]; c.iquat[k] = bf[10 + k]; }
-  c.mass = bf[14];
+  for (int k = 0; k < 4; ++k) c.quat[k] = bf[3 + k];
+  const int j = c.jn > 0 ? c.jadr : 0;
+  const int* ji = T.jnt_i + 4 * j;
+  const float* jf = T.jnt_f + 8 * j;
+  c.jtype0 = c.jn > 0 ? ji[0] : 3; c.jqa0 = ji[1]; c.jda0 = ji[2];
 #pragma unroll
-  for (int jj = 0; jj < 3; ++jj) {
-    const bool jok = jj < c.jn;
-    const int j = jok ? bi[1] + jj : 0;
-    const int* ji = T.jnt_i + 4 * j;
-    const float* jf = T.jnt_f + 8 * j;
-    c.jtype[jj] = jok ? ji[0] : 3; c.jqa[jj] = ji[1]; c.jda[jj] = ji[2];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { c.jpos[jj][k] = jf[k]; c.jaxis[jj][k] = jf[3 + k]; }
-    c.jq0[jj] = jf[6];
-  }
+  for (int k = 0; k < 3; ++k) { c.jpos0[k] = jf[k]; c.jaxis0[k] = jf[3 + k]; }
   return c;
 }
 
@@ -225,8 +223,11 @@ struct Wave {
   const RRTables& T;
   const int lane;
   float* const lds;
-  float *s_qpos, *s_qvel, *s_act, *s_ctrl, *s_xpos, *s_xquat, *s_xmat, *s_cinert, *s_crb, *s_cdof, *s_cvel, *s_cacc,
-      *s_cfrc, *s_buf, *s_qM, *s_qLD, *s_J, *s_cf, *s_vec, *s_x, *s_y, *s_arm;
+  // LDS regions.  Aliases (liveness): s_crb == s_cinert (accumulated in place once cinert has been
+  // consumed / written out), s_cacc|s_cfrc and the sin/cos scratch live in the region that later holds qLD,
+  // s_buf reuses xpos|xquat after the contact geometry has been taken.
+  float *s_qpos, *s_qvel, *s_act, *s_ctrl, *s_xpos, *s_xquat, *s_cinert, *s_crb, *s_cdof, *s_cvel, *s_cacc,
+      *s_cfrc, *s_buf, *s_sc, *s_qM, *s_qLD, *s_vec, *s_x, *s_y, *s_arm;
   static constexpr int W = NVS * RR_LANES;
   static constexpr int WC = NCS * RR_LANES;
 
@@ -241,8 +242,6 @@ struct Wave {
   int con_chain[NCS][9];  // ancestor dof chain of the contact's body, leaf first, 4 dof ids per register
   // per-dof registers (slot s -> dof lane + 64 s)
   int dofdepth[NVS], dofmadr[NVS], doflast[NVS];
-  static constexpr int RR_TRI = 10;   // (p,q) pairs of chains up to depth 35 (630 pairs) live in registers
-  int tri_r[RR_TRI];
   float dinv[NVS];
   float qfrc_smooth[NVS], qfrc_actuator[NVS], qacc_smooth[NVS], act_dot[NVS];
   float qacc[NVS], Ma[NVS], grad[NVS], Mgrad[NVS], search[NVS], mv[NVS], qfrc_con[NVS], warm[NVS];
@@ -252,8 +251,9 @@ struct Wave {
   // contact rows (4 pyramid rows per contact slot)
   bool con_act[NCS];
   float con_mu[NCS], con_D[NCS], con_aref[NCS][4], con_jar[NCS][4], con_jv[NCS][4];
-  int con_jadr[NCS], con_nanc[NCS];
-  unsigned long long amask[NCS];
+  float con_kk[NCS], con_b[NCS];                 // k*imp*dist and b of the contact's reference acceleration
+  float con_off[NCS][3], con_fr[NCS][9];         // contact point relative to the tree's COM; frame rows n, t1, t2
+  int con_nanc[NCS];
   float com0[3], com1[3];
   float gauss, cost, prev_cost;
   unsigned long long pt_last, pt[RR_NPH];
@@ -264,9 +264,9 @@ struct Wave {
   __device__ Wave(const RRDims& d, const RRTables& t, float* l)
       : D(d), T(t), lane(threadIdx.x), lds(l) {
     s_qpos = l + d.o_qpos; s_qvel = l + d.o_qvel; s_act = l + d.o_act; s_ctrl = l + d.o_ctrl;
-    s_xpos = l + d.o_xpos; s_xquat = l + d.o_xquat; s_xmat = l + d.o_xmat; s_cinert = l + d.o_cinert;
-    s_crb = l + d.o_crb; s_cdof = l + d.o_cdof; s_cvel = l + d.o_cvel; s_cacc = l + d.o_cacc; s_cfrc = l + d.o_cfrc;
-    s_buf = l + d.o_buf; s_qM = l + d.o_qM; s_qLD = l + d.o_qLD; s_J = l + d.o_J; s_cf = l + d.o_cf;
+    s_xpos = l + d.o_xpos; s_xquat = l + d.o_xquat; s_cinert = l + d.o_cinert; s_crb = s_cinert;
+    s_cdof = l + d.o_cdof; s_cvel = l + d.o_cvel; s_qM = l + d.o_qM; s_qLD = l + d.o_qLD;
+    s_cacc = s_qLD; s_cfrc = s_qLD + 6 * d.nbody; s_sc = s_qLD; s_buf = s_xpos;
     s_vec = l + d.o_vec; s_x = l + d.o_x; s_y = l + d.o_y; s_arm = l + d.o_arm;
   }
 
@@ -279,20 +279,15 @@ struct Wave {
   __device__ __forceinline__ v3 get_com(int r) const {
     return mk3(r ? com1[0] : com0[0], r ? com1[1] : com0[1], r ? com1[2] : com0[2]);
   }
-  __device__ __forceinline__ bool con_bit(int c) const {
-    unsigned long long mk = amask[0];
-#pragma unroll
-    for (int i = 1; i < NCS; ++i) mk = (c >> 6) == i ? amask[i] : mk;
-    return (mk >> (c & 63)) & 1ull;
-  }
   // p-th ancestor dof (leaf first) of contact slot cs; p is a compile-time constant after unrolling
-  __device__ __forceinline__ int chain_at(int cs, int p) const { return (con_chain[cs][p >> 2] >> (8 * (p & 3))) & 255; }
+  __device__ __forceinline__ int chain_at(int cs, int p) const { return (opaque(con_chain[cs][p >> 2]) >> (8 * (p & 3))) & 255; }
   // wave-uniform predicate -> scalar branch
   static __device__ __forceinline__ bool uni(bool p) { return __builtin_amdgcn_readfirstlane((int)p) != 0; }
 
   // ---------------------------------------------------------------- A-1 kinematics (level sweep)
   // Lane b owns body b for every level; its constants are in registers, so a level costs only the
-  // LDS hand-off from the parent (no table or parameter loads).
+  // LDS hand-off of the parent's (pos, quat).  Rotation matrices are rebuilt from the quaternion where needed
+  // (xmat is not stored: LDS budget).
   __device__ __forceinline__ void kinematics() {
     // half-angle sin / cos of every hinge, one joint per lane, before the serial level sweep
 #pragma unroll
@@ -300,8 +295,8 @@ struct Wave {
       const int d = lane + RR_LANES * s;
       if (d < D.nv && dofkind[s] == 6) {
         const float ang = s_qpos[dofqadr[s]] - dofq0[s];
-        s_buf[2 * d] = sinf(ang * 0.5f);
-        s_buf[2 * d + 1] = cosf(ang * 0.5f);
+        s_sc[2 * d] = sinf(ang * 0.5f);
+        s_sc[2 * d + 1] = cosf(ang * 0.5f);
       }
     }
     sync();
@@ -314,47 +309,51 @@ struct Wave {
           if (on) {
             const int b = lane + RR_LANES * s, p = c.parent;
             float quat[4], mat[9], pq[4];
-            v3 pos = ld3(s_xpos + 3 * p) + mat_vec(s_xmat + 9 * p, mk3(c.pos[0], c.pos[1], c.pos[2]));
 #pragma unroll
             for (int k = 0; k < 4; ++k) pq[k] = s_xquat[4 * p + k];
+            quat_to_mat(mat, pq);
+            v3 pos = ld3(s_xpos + 3 * p) + mat_vec(mat, mk3(c.pos[0], c.pos[1], c.pos[2]));
             quat_mul(quat, pq, c.quat);
             int free_da = -1;
+            for (int jj = 0; jj < c.jn; ++jj) {
+              int jt, qa, da;
+              v3 jp, ja;
+              if (jj == 0) {
+                jt = c.jtype0; qa = c.jqa0; da = c.jda0;
+                jp = mk3(c.jpos0[0], c.jpos0[1], c.jpos0[2]); ja = mk3(c.jaxis0[0], c.jaxis0[1], c.jaxis0[2]);
+              } else {   // 2nd / 3rd joint of a multi-joint body: parameters from the tables
+                const int* ji = T.jnt_i + 4 * (c.jadr + jj);
+                const float* jf = T.jnt_f + 8 * (c.jadr + jj);
+                jt = ji[0]; qa = ji[1]; da = ji[2];
+                jp = ld3(jf); ja = ld3(jf + 3);
+              }
+              if (jt == 0) {  // free
+                pos = ld3(s_qpos + qa);
 #pragma unroll
-            for (int jj = 0; jj < 3; ++jj) {
-              if (jj < c.jn) {
-                const int qa = c.jqa[jj], da = c.jda[jj];
-                if (c.jtype[jj] == 0) {  // free
-                  pos = ld3(s_qpos + qa);
+                for (int k = 0; k < 4; ++k) quat[k] = s_qpos[qa + 3 + k];
+                quat_normalize(quat);
+                free_da = da;
+              } else {  // hinge
+                quat_to_mat(mat, quat);
+                const v3 anchor = mat_vec(mat, jp) + pos;
+                const v3 axis = mat_vec(mat, ja);
+                st3(s_cdof + 6 * da, axis);        // raw: axis ; anchor (finalised in com_pos)
+                st3(s_cdof + 6 * da + 3, anchor);
+                const float sn = s_sc[2 * da], cs = s_sc[2 * da + 1];
+                float ql[4] = {cs, ja.x * sn, ja.y * sn, ja.z * sn}, qn[4];
+                quat_mul(qn, quat, ql);
 #pragma unroll
-                  for (int k = 0; k < 4; ++k) quat[k] = s_qpos[qa + 3 + k];
-                  quat_normalize(quat);
-                  free_da = da;
-                } else {  // hinge
-                  const v3 jp = mk3(c.jpos[jj][0], c.jpos[jj][1], c.jpos[jj][2]);
-                  const v3 ja = mk3(c.jaxis[jj][0], c.jaxis[jj][1], c.jaxis[jj][2]);
-                  quat_to_mat(mat, quat);
-                  const v3 anchor = mat_vec(mat, jp) + pos;
-                  const v3 axis = mat_vec(mat, ja);
-                  st3(s_cdof + 6 * da, axis);        // raw: axis ; anchor (finalised in com_pos)
-                  st3(s_cdof + 6 * da + 3, anchor);
-                  const float sn = s_buf[2 * da], cs = s_buf[2 * da + 1];
-                  float ql[4] = {cs, ja.x * sn, ja.y * sn, ja.z * sn}, qn[4];
-                  quat_mul(qn, quat, ql);
-#pragma unroll
-                  for (int k = 0; k < 4; ++k) quat[k] = qn[k];
-                  quat_to_mat(mat, quat);
-                  pos = anchor - mat_vec(mat, jp);
-                }
+                for (int k = 0; k < 4; ++k) quat[k] = qn[k];
+                quat_to_mat(mat, quat);
+                pos = anchor - mat_vec(mat, jp);
               }
             }
             quat_normalize(quat);
-            quat_to_mat(mat, quat);
             st3(s_xpos + 3 * b, pos);
 #pragma unroll
             for (int k = 0; k < 4; ++k) s_xquat[4 * b + k] = quat[k];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) s_xmat[9 * b + k] = mat[k];
             if (free_da >= 0) {
+              quat_to_mat(mat, quat);
 #pragma unroll
               for (int k = 0; k < 3; ++k) {
                 st3(s_cdof + 6 * (free_da + 3 + k), mk3(mat[k], mat[3 + k], mat[6 + k]));
@@ -376,13 +375,16 @@ struct Wave {
     for (int s = 0; s < NBS; ++s) {
       const int b = lane + RR_LANES * s;
       xip[s][0] = xip[s][1] = xip[s][2] = 0;
-      if (s > 0 && !__any(b >= 1 && b < D.nbody)) continue;
-      const BodyC c = s == 0 ? bc0 : load_bodyc(T, b, D.nbody);
       if (b >= 1 && b < D.nbody) {
-        v3 xi = ld3(s_xpos + 3 * b) + mat_vec(s_xmat + 9 * b, mk3(c.ipos[0], c.ipos[1], c.ipos[2]));
+        const float* bf = T.body_f + 18 * b;
+        float bq[4], R[9];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bq[k] = s_xquat[4 * b + k];
+        quat_to_mat(R, bq);
+        v3 xi = ld3(s_xpos + 3 * b) + mat_vec(R, ld3(bf + 7));
         xip[s][0] = xi.x; xip[s][1] = xi.y; xip[s][2] = xi.z;
-        const float mass = c.mass;
-        if (c.root == 0) { acc[0][0] += mass * xi.x; acc[0][1] += mass * xi.y; acc[0][2] += mass * xi.z; }
+        const float mass = bf[14];
+        if (T.body_i[RR_BODYI * b + 5] == 0) { acc[0][0] += mass * xi.x; acc[0][1] += mass * xi.y; acc[0][2] += mass * xi.z; }
         else                { acc[1][0] += mass * xi.x; acc[1][1] += mass * xi.y; acc[1][2] += mass * xi.z; }
       }
     }
@@ -394,17 +396,16 @@ struct Wave {
 #pragma unroll
     for (int s = 0; s < NBS; ++s) {
       const int b = lane + RR_LANES * s;
-      if (s > 0 && !__any(b >= 1 && b < D.nbody)) continue;
-      const BodyC c = s == 0 ? bc0 : load_bodyc(T, b, D.nbody);
       if (b >= 1 && b < D.nbody) {
-        float q[4], bq[4], R[9];
+        const float* bf = T.body_f + 18 * b;
+        float q[4], bq[4], iq[4], R[9];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) bq[k] = s_xquat[4 * b + k];
-        quat_mul(q, bq, c.iquat);
+        for (int k = 0; k < 4; ++k) { bq[k] = s_xquat[4 * b + k]; iq[k] = bf[10 + k]; }
+        quat_mul(q, bq, iq);
         quat_to_mat(R, q);
-        const float mass = c.mass;
-        const float I0 = c.inertia[0], I1 = c.inertia[1], I2 = c.inertia[2];
-        const v3 cm = get_com(c.root);
+        const float mass = bf[14];
+        const float I0 = bf[15], I1 = bf[16], I2 = bf[17];
+        const v3 cm = get_com(T.body_i[RR_BODYI * b + 5]);
         const float d0 = xip[s][0] - cm.x, d1 = xip[s][1] - cm.y, d2 = xip[s][2] - cm.z;
         float t[9];
 #pragma unroll
@@ -452,7 +453,7 @@ struct Wave {
             float v[6], a[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) { v[k] = s_cvel[6 * p + k]; a[k] = s_cacc[6 * p + k]; }
-            const bool is_free = c.jn > 0 && c.jtype[0] == 0;
+            const bool is_free = c.jn > 0 && c.jtype0 == 0;
             if (is_free) {
               for (int k = 0; k < 3; ++k) {
                 const float qv = s_qvel[da + k];
@@ -498,8 +499,7 @@ struct Wave {
   // siblings take turns (largest id first = the reference's accumulation order), so no two lanes touch
   // the same parent in one step.
   __device__ __forceinline__ void backward_sweep() {
-    for (int e = lane; e < 10 * D.nbody; e += RR_LANES) s_crb[e] = s_cinert[e];
-    sync();
+    // composite inertia accumulates IN PLACE in the cinert region (cinert itself has been consumed / written out)
     for (int st = 0; st < D.nbwd; ++st) {
       const int code = st < RR_LANES ? __builtin_amdgcn_readlane(bwd_step_r[0], st & 63) : __builtin_amdgcn_readlane(bwd_step_r[1], st & 63);
       const int L = code & 255, r = code >> 8;
@@ -531,7 +531,7 @@ struct Wave {
     sync();
 #pragma unroll
     for (int it = 0; it < NME; ++it) {
-      const int ij = ment[it];
+      const int ij = opaque(ment[it]);
       if (ij >= 0) {
         const int i = ij & 255, j = ij >> 8;
         float v = dot6(s_cdof + 6 * j, s_buf + 6 * i);
@@ -589,7 +589,7 @@ struct Wave {
     sync();
 #pragma unroll
     for (int it = 0; it < NME; ++it) {
-      const int ij = ment[it];
+      const int ij = opaque(ment[it]);
       if (ij >= 0) {
         const int i = ij & 255, j = ij >> 8;
         if (i != j) s_qLD[lane + RR_LANES * it] *= s_arm[D.nv + i];
@@ -657,7 +657,7 @@ struct Wave {
     sync();
 #pragma unroll
     for (int it = 0; it < NME; ++it) {
-      const int ij = ment[it];
+      const int ij = opaque(ment[it]);
       if (ij >= 0) {
         const int i = ij & 255, j = ij >> 8;
         const float mij = s_qM[lane + RR_LANES * it];
@@ -711,54 +711,35 @@ struct Wave {
     }
   }
 
-  // ---------------------------------------------------------------- A-4/A-5 collision + constraint rows
-  __device__ __forceinline__ void constraints(float* dbg) {
-    // joint limits
-#pragma unroll
-    for (int s = 0; s < NVS; ++s) {
-      const int d = lane + RR_LANES * s;
-      lim_act[s] = false; lim_sign[s] = 0; lim_D[s] = 0; lim_aref[s] = 0; lim_jar[s] = 0; lim_jv[s] = 0;
-      if (d < D.nv) {
-        const int* di = T.dof_i + RR_DOFI * d;
-        if (di[8]) {
-          const float* df = T.dof_f + 16 * d;
-          const float q = s_qpos[di[6]];
-          const float dmin_ = q - df[4], dmax_ = df[5] - q;
-          const float pos = fminf(dmin_, dmax_);
-          if (pos < 0) {
-            float k, b, imp;
-            kbi(D.dt, df[6], df[7], df + 8, pos, k, b, imp);
-            const float r = fmaxf(df[13] * (1.0f - imp) / imp, RR_MINVAL);
-            lim_act[s] = true;
-            lim_sign[s] = dmin_ < dmax_ ? 1.0f : -1.0f;
-            lim_D[s] = 1.0f / r;
-            lim_aref[s] = -b * (lim_sign[s] * s_qvel[d]) - k * imp * pos;
-          }
-          if (dbg) { dbg[D.g_lim + 3 * d] = pos; dbg[D.g_lim + 3 * d + 1] = lim_D[s]; dbg[D.g_lim + 3 * d + 2] = lim_aref[s]; }
-        }
-      }
-    }
-    // contacts
+  // ---------------------------------------------------------------- A-4 collision: contact geometry -> registers
+  // Runs right after com_pos while xpos / xquat are still live; the Jacobian is never materialised: a contact keeps
+  // its offset from the tree COM and its frame, and J x / J' f are evaluated on the fly from cdof (J-free products).
+  __device__ __forceinline__ void contact_geometry(float* dbg) {
 #pragma unroll
     for (int cs = 0; cs < NCS; ++cs) {
       const int c = lane + RR_LANES * cs;
-      con_act[cs] = false; con_mu[cs] = 0; con_D[cs] = 0; con_jadr[cs] = 0; con_nanc[cs] = 0;
+      con_act[cs] = false; con_mu[cs] = 0; con_D[cs] = 0; con_nanc[cs] = 0; con_kk[cs] = 0; con_b[cs] = 0;
+#pragma unroll
       for (int k = 0; k < 4; ++k) { con_aref[cs][k] = 0; con_jar[cs][k] = 0; con_jv[cs][k] = 0; }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) con_off[cs][k] = 0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) con_fr[cs][k] = 0;
       if (c < D.ncon) {
         const int* ci = T.con_i + 8 * c;
         const float* cf = T.con_f + 26 * c;
         const int kind = ci[0], b = ci[1], r = ci[2];
-        float gq[4], bq[4], q[4], gm[9];
-        const float* xm = s_xmat + 9 * b;
-        v3 gp = ld3(s_xpos + 3 * b) + mat_vec(xm, ld3(cf));
+        float gq[4], bq[4], q[4], gm[9], xm[9];
+#pragma unroll
         for (int k = 0; k < 4; ++k) { bq[k] = s_xquat[4 * b + k]; gq[k] = cf[3 + k]; }
+        quat_to_mat(xm, bq);
+        v3 gp = ld3(s_xpos + 3 * b) + mat_vec(xm, ld3(cf));
         quat_mul(q, bq, gq);
         quat_to_mat(gm, q);
         const v3 size = ld3(cf + 7), n = ld3(cf + 10), pp = ld3(cf + 13);
         v3 fb, pos;
         float dist;
-        // default tangent from make_frame(n)
-        v3 yb = (n.y > -0.5f && n.y < 0.5f) ? mk3(0, 1, 0) : mk3(0, 0, 1);
+        v3 yb = (n.y > -0.5f && n.y < 0.5f) ? mk3(0, 1, 0) : mk3(0, 0, 1);   // default tangent of make_frame(n)
         if (kind == 3) {  // plane - ellipsoid
           v3 sdir = mk3((gm[0] * n.x + gm[3] * n.y + gm[6] * n.z) * size.x, (gm[1] * n.x + gm[4] * n.y + gm[7] * n.z) * size.y,
                         (gm[2] * n.x + gm[5] * n.y + gm[8] * n.z) * size.z);
@@ -794,57 +775,72 @@ struct Wave {
         }
         if (dist < 0) {
           con_act[cs] = true;
-          const float mu = cf[16];
           float k, bcoef, imp;
           kbi(D.dt, cf[18], cf[19], cf + 20, dist, k, bcoef, imp);
           const float rr = fmaxf(cf[17] * (1.0f - imp) / imp, RR_MINVAL);
-          con_mu[cs] = mu; con_D[cs] = 1.0f / rr;
-          const int nanc = ci[4], jadr = ci[5];
-          con_jadr[cs] = jadr; con_nanc[cs] = nanc;
+          con_mu[cs] = cf[16]; con_D[cs] = 1.0f / rr; con_nanc[cs] = ci[4];
+          con_kk[cs] = k * imp * dist; con_b[cs] = bcoef;
           const v3 off = pos - get_com(r);
-          float jnv = 0, j1v = 0, j2v = 0;
-#pragma unroll
-          for (int p0 = 0; p0 < 36; p0 += 4) {
-            if (__any(p0 < nanc)) {
-#pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                const int p = p0 + u;
-                if (p < nanc) {
-                  const int dd = chain_at(cs, p);
-                  const float* cd = s_cdof + 6 * dd;
-                  const v3 jp = ld3(cd + 3) + cross(ld3(cd), off);
-                  const float jn = dot(n, jp), j1 = dot(fb, jp), j2 = dot(fc, jp);
-                  s_J[jadr + 3 * p] = jn; s_J[jadr + 3 * p + 1] = j1; s_J[jadr + 3 * p + 2] = j2;
-                  const float qv = s_qvel[dd];
-                  jnv += jn * qv; j1v += j1 * qv; j2v += j2 * qv;
-                }
-              }
-            }
-          }
-          const float kk = k * imp * dist;
-          con_aref[cs][0] = -bcoef * (jnv + mu * j1v) - kk;
-          con_aref[cs][1] = -bcoef * (jnv - mu * j1v) - kk;
-          con_aref[cs][2] = -bcoef * (jnv + mu * j2v) - kk;
-          con_aref[cs][3] = -bcoef * (jnv - mu * j2v) - kk;
+          con_off[cs][0] = off.x; con_off[cs][1] = off.y; con_off[cs][2] = off.z;
+          con_fr[cs][0] = n.x; con_fr[cs][1] = n.y; con_fr[cs][2] = n.z;
+          con_fr[cs][3] = fb.x; con_fr[cs][4] = fb.y; con_fr[cs][5] = fb.z;
+          con_fr[cs][6] = fc.x; con_fr[cs][7] = fc.y; con_fr[cs][8] = fc.z;
         }
-        if (dbg) {
-          dbg[D.g_con_D + c] = con_D[cs];
-          for (int k = 0; k < 4; ++k) dbg[D.g_con_aref + 4 * c + k] = con_aref[cs][k];
-        }
+        if (dbg) dbg[D.g_con_D + c] = con_D[cs];
       }
-      amask[cs] = __ballot(con_act[cs]);
     }
-    sync();
   }
 
-  // rows of J * s_vec for this lane's contacts (pyramid rows) ; s_vec visible
-  __device__ __forceinline__ void jac_mul(float (*out)[4]) {
+  // ---------------------------------------------------------------- A-5 constraint rows (limits; contact aref)
+  __device__ __forceinline__ void constraint_rows(float* dbg) {
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) {
+      const int d = lane + RR_LANES * s;
+      lim_act[s] = false; lim_sign[s] = 0; lim_D[s] = 0; lim_aref[s] = 0; lim_jar[s] = 0; lim_jv[s] = 0;
+      if (d < D.nv) {
+        const int* di = T.dof_i + RR_DOFI * d;
+        if (di[8]) {
+          const float* df = T.dof_f + 16 * d;
+          const float q = s_qpos[di[6]];
+          const float dmin_ = q - df[4], dmax_ = df[5] - q;
+          const float pos = fminf(dmin_, dmax_);
+          if (pos < 0) {
+            float k, b, imp;
+            kbi(D.dt, df[6], df[7], df + 8, pos, k, b, imp);
+            const float r = fmaxf(df[13] * (1.0f - imp) / imp, RR_MINVAL);
+            lim_act[s] = true;
+            lim_sign[s] = dmin_ < dmax_ ? 1.0f : -1.0f;
+            lim_D[s] = 1.0f / r;
+            lim_aref[s] = -b * (lim_sign[s] * s_qvel[d]) - k * imp * pos;
+          }
+          if (dbg) { dbg[D.g_lim + 3 * d] = pos; dbg[D.g_lim + 3 * d + 1] = lim_D[s]; dbg[D.g_lim + 3 * d + 2] = lim_aref[s]; }
+        }
+      }
+    }
+    float jq[NCS][4];
+    jac_mul(jq, s_qvel);      // J * qvel, pyramid rows
+#pragma unroll
+    for (int cs = 0; cs < NCS; ++cs) {
+      if (con_act[cs]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) con_aref[cs][k] = -con_b[cs] * jq[cs][k] - con_kk[cs];
+      }
+      const int c = lane + RR_LANES * cs;
+      if (dbg && c < D.ncon) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dbg[D.g_con_aref + 4 * c + k] = con_aref[cs][k];
+      }
+    }
+  }
+
+  // pyramid rows of J * vec for this lane's contacts, J-free: the spatial velocity of the contact body induced by `vec`
+  // (sum of cdof * vec over the ancestor chain), taken at the contact point and projected on the frame
+  __device__ __forceinline__ void jac_mul(float (*out)[4], const float* vec) {
 #pragma unroll
     for (int cs = 0; cs < NCS; ++cs) {
       out[cs][0] = out[cs][1] = out[cs][2] = out[cs][3] = 0.0f;
       if (con_act[cs]) {
-        float jn = 0, j1 = 0, j2 = 0;
-        const int jadr = con_jadr[cs];
+        float w[6] = {0, 0, 0, 0, 0, 0};
         const int nanc = con_nanc[cs];
 #pragma unroll
         for (int p0 = 0; p0 < 36; p0 += 4) {
@@ -853,12 +849,19 @@ struct Wave {
             for (int u = 0; u < 4; ++u) {
               const int p = p0 + u;
               if (p < nanc) {
-                const float xv = s_vec[chain_at(cs, p)];
-                jn += s_J[jadr + 3 * p] * xv; j1 += s_J[jadr + 3 * p + 1] * xv; j2 += s_J[jadr + 3 * p + 2] * xv;
+                const int dd = chain_at(cs, p);
+                const float xv = vec[dd];
+                const float* cd = s_cdof + 6 * dd;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) w[i] += cd[i] * xv;
               }
             }
           }
         }
+        const v3 pv = mk3(w[3], w[4], w[5]) + cross(mk3(w[0], w[1], w[2]), mk3(con_off[cs][0], con_off[cs][1], con_off[cs][2]));
+        const float jn = dot(mk3(con_fr[cs][0], con_fr[cs][1], con_fr[cs][2]), pv);
+        const float j1 = dot(mk3(con_fr[cs][3], con_fr[cs][4], con_fr[cs][5]), pv);
+        const float j2 = dot(mk3(con_fr[cs][6], con_fr[cs][7], con_fr[cs][8]), pv);
         const float mu = con_mu[cs];
         out[cs][0] = jn + mu * j1; out[cs][1] = jn - mu * j1; out[cs][2] = jn + mu * j2; out[cs][3] = jn - mu * j2;
       }
@@ -882,16 +885,22 @@ struct Wave {
         }
         const float mu = con_mu[cs];
         const float fn = f[0] + f[1] + f[2] + f[3], f1 = mu * (f[0] - f[1]), f2 = mu * (f[2] - f[3]);
-        if (fn != 0.0f) {   // J' f of this contact scattered along its ancestor chain (LDS float atomics)
-          const int jadr = con_jadr[cs], nanc = con_nanc[cs];
+        if (fn != 0.0f) {   // J' f: the contact force as a spatial force about the tree COM, dotted with cdof along the chain
+          const int nanc = con_nanc[cs];
+          const v3 F = mk3(con_fr[cs][0], con_fr[cs][1], con_fr[cs][2]) * fn + mk3(con_fr[cs][3], con_fr[cs][4], con_fr[cs][5]) * f1 +
+                       mk3(con_fr[cs][6], con_fr[cs][7], con_fr[cs][8]) * f2;
+          const v3 tau = cross(mk3(con_off[cs][0], con_off[cs][1], con_off[cs][2]), F);
 #pragma unroll
           for (int p0 = 0; p0 < 36; p0 += 4) {
             if (__any(p0 < nanc)) {
 #pragma unroll
               for (int u = 0; u < 4; ++u) {
                 const int p = p0 + u;
-                if (p < nanc)
-                  atomicAdd(s_y + chain_at(cs, p), s_J[jadr + 3 * p] * fn + s_J[jadr + 3 * p + 1] * f1 + s_J[jadr + 3 * p + 2] * f2);
+                if (p < nanc) {
+                  const int dd = chain_at(cs, p);
+                  const float* cd = s_cdof + 6 * dd;
+                  atomicAdd(s_y + dd, dot(ld3(cd), tau) + dot(ld3(cd + 3), F));
+                }
               }
             }
           }
@@ -927,7 +936,7 @@ struct Wave {
   // [UP mjx solver._Context.create]: Jaref, Ma, constraint state (and gradient/search) at `qacc`
   __device__ __forceinline__ void ctx_create(bool with_grad) {
     put_vec(qacc);
-    jac_mul(con_jar);
+    jac_mul(con_jar, s_vec);
 #pragma unroll
     for (int cs = 0; cs < NCS; ++cs)
 #pragma unroll
@@ -990,7 +999,7 @@ struct Wave {
     float red[4] = {0, 0, 0, 0};
     put_vec(search);
     mul_m(mv);
-    jac_mul(con_jv);
+    jac_mul(con_jv, s_vec);
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
       lim_jv[s] = lim_sign[s] * search[s];
@@ -1136,7 +1145,7 @@ struct Wave {
 
 // ------------------------------------------------------------------------------------------ kernel
 template <int NBS, int NVS, int NCS, bool PROF>
-__global__ __launch_bounds__(RR_LANES) void rr_step_kernel(const RRDims D, const RRTables T, const RRIO io, const int num_envs,
+__global__ __launch_bounds__(RR_LANES, 2) void rr_step_kernel(const RRDims D, const RRTables T, const RRIO io, const int num_envs,
                                                            const int n_frames) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int env = blockIdx.x;
@@ -1189,15 +1198,8 @@ __global__ __launch_bounds__(RR_LANES) void rr_step_kernel(const RRDims D, const
 #pragma unroll
     for (int k = 0; k < 9; ++k) w.con_chain[cs][k] = T.con_chain_packed[k * (NCS * RR_LANES) + cs * RR_LANES + lane];
   for (int i = lane; i < D.nv; i += RR_LANES) w.s_arm[i] = T.dof_f[16 * i];
-#pragma unroll
-  for (int i = 0; i < Wave<NBS, NVS, NCS>::RR_TRI; ++i) { const int t = lane + RR_LANES * i; w.tri_r[i] = t < D.ntri ? T.tri[t] : 0; }
-  if (lane == 0) {  // world body
-    for (int k = 0; k < 3; ++k) w.s_xpos[k] = 0.0f;
-    w.s_xquat[0] = 1.0f; w.s_xquat[1] = w.s_xquat[2] = w.s_xquat[3] = 0.0f;
-    for (int k = 0; k < 9; ++k) w.s_xmat[k] = (k % 4 == 0) ? 1.0f : 0.0f;
-    for (int k = 0; k < 6; ++k) { w.s_cvel[k] = 0.0f; w.s_cfrc[k] = 0.0f; }
-    w.s_cacc[0] = w.s_cacc[1] = w.s_cacc[2] = 0.0f;
-    w.s_cacc[3] = -D.gx; w.s_cacc[4] = -D.gy; w.s_cacc[5] = -D.gz;
+  if (lane == 0) {  // world body entries that no phase overwrites
+    for (int k = 0; k < 6; ++k) w.s_cvel[k] = 0.0f;
     for (int k = 0; k < 10; ++k) w.s_cinert[k] = 0.0f;
   }
   w.sync();
@@ -1205,36 +1207,81 @@ __global__ __launch_bounds__(RR_LANES) void rr_step_kernel(const RRDims D, const
   if (PROF) { for (int i = 0; i < RR_NPH; ++i) w.pt[i] = 0; w.pt_last = __builtin_readcyclecounter(); }
   const int frames = (io.mode & 1) ? n_frames : 1;
   int niter = 0;
+  float xq1[4] = {1, 0, 0, 0};   // xquat of body 1 at the last forward pass (obs: xmat[1])
   for (int f = 0; f < frames; ++f) {
-    float* dg = (f == frames - 1) ? dbg : nullptr;
+    const bool last = f == frames - 1;
+    float* dg = last ? dbg : nullptr;
     float bias[NVS], passive[NVS];
     w.template stamp<PROF>(15);
+    if (lane == 0) {  // world body pose (its LDS cells are reused by later phases of every substep)
+      for (int k = 0; k < 3; ++k) w.s_xpos[k] = 0.0f;
+      w.s_xquat[0] = 1.0f; w.s_xquat[1] = w.s_xquat[2] = w.s_xquat[3] = 0.0f;
+    }
     w.kinematics();
     w.template stamp<PROF>(0);
     w.com_pos();
     w.template stamp<PROF>(1);
+    if (last) {   // pose outputs of the last forward pass, before the pose cells are recycled
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xq1[k] = w.s_xquat[4 + k];
+      if (io.o_xpos) for (int e = lane; e < 3 * D.nbody; e += RR_LANES) io.o_xpos[(size_t)env * 3 * D.nbody + e] = w.s_xpos[e];
+      if (io.o_xmat || dg) {
+        for (int b = lane; b < D.nbody; b += RR_LANES) {
+          float q[4], mm[9];
+          for (int k = 0; k < 4; ++k) q[k] = w.s_xquat[4 * b + k];
+          quat_to_mat(mm, q);
+          for (int k = 0; k < 9; ++k) {
+            if (io.o_xmat) io.o_xmat[(size_t)env * 9 * D.nbody + 9 * b + k] = mm[k];
+            if (dg) dg[D.g_xmat + 9 * b + k] = mm[k];
+          }
+        }
+      }
+      if (io.o_com && lane == 0) for (int k = 0; k < 3; ++k) io.o_com[(size_t)env * 3 + k] = w.com0[k];
+      if (dg) {
+        for (int e = lane; e < 3 * D.nbody; e += RR_LANES) dg[D.g_xpos + e] = w.s_xpos[e];
+        for (int e = lane; e < 4 * D.nbody; e += RR_LANES) dg[D.g_xquat + e] = w.s_xquat[e];
+        for (int e = lane; e < 10 * D.nbody; e += RR_LANES) dg[D.g_cinert + e] = w.s_cinert[e];
+        for (int e = lane; e < 6 * D.nv; e += RR_LANES) dg[D.g_cdof + e] = w.s_cdof[e];
+        if (lane == 0) { for (int k = 0; k < 3; ++k) { dg[D.g_com + k] = w.com0[k]; dg[D.g_com + 3 + k] = w.com1[k]; } }
+      }
+    }
+    w.contact_geometry(dg);
+    if (lane == 0) {  // world body acceleration = -gravity (cacc shares its cells with qLD)
+      w.s_cacc[0] = w.s_cacc[1] = w.s_cacc[2] = 0.0f;
+      w.s_cacc[3] = -D.gx; w.s_cacc[4] = -D.gy; w.s_cacc[5] = -D.gz;
+    }
+    w.sync();
     w.velocity_sweep();
     w.template stamp<PROF>(2);
+    if (last) {   // cinert / cvel of the last forward pass go out now: cinert's cells become the composite inertia next
+      if (io.o_cinert) for (int e = lane; e < 10 * D.nbody; e += RR_LANES) io.o_cinert[(size_t)env * 10 * D.nbody + e] = w.s_cinert[e];
+      if (io.o_cvel) for (int e = lane; e < 6 * D.nbody; e += RR_LANES) io.o_cvel[(size_t)env * 6 * D.nbody + e] = w.s_cvel[e];
+      if (io.obs) {
+        float* ob = io.obs + (size_t)env * D.obs_dim + D.nq + D.nv;
+        for (int i = lane; i < 10 * (D.nbody - 1); i += RR_LANES) ob[i] = w.s_cinert[10 + i];
+        ob += 10 * (D.nbody - 1);
+        for (int i = lane; i < 6 * (D.nbody - 1); i += RR_LANES) ob[i] = w.s_cvel[6 + i];
+      }
+      if (dg) for (int e = lane; e < 6 * D.nbody; e += RR_LANES) dg[D.g_cvel + e] = w.s_cvel[e];
+    }
     w.backward_sweep();
     w.template stamp<PROF>(3);
+    w.smooth_forces(bias, passive);     // needs cfrc, whose cells the factorisation overwrites
+    if (dg) {
+      for (int e = lane; e < 10 * D.nbody; e += RR_LANES) dg[D.g_crb + e] = w.s_crb[e];
+      for (int e = lane; e < 6 * D.nbody; e += RR_LANES) dg[D.g_cfrc + e] = w.s_cfrc[e];
+    }
+    w.sync();
     w.mass_matrix();
     w.template stamp<PROF>(4);
     w.factor(0.0f);
     w.template stamp<PROF>(5);
-    w.smooth_forces(bias, passive);
 #pragma unroll
     for (int s = 0; s < NVS; ++s) w.qacc_smooth[s] = w.qfrc_smooth[s];
     w.ldl_solve(w.qacc_smooth);
     w.template stamp<PROF>(6);
-    if (dg) {  // dump before the solver / integrator reuse buffers
-      for (int e = lane; e < 3 * D.nbody; e += RR_LANES) dg[D.g_xpos + e] = w.s_xpos[e];
-      for (int e = lane; e < 4 * D.nbody; e += RR_LANES) dg[D.g_xquat + e] = w.s_xquat[e];
-      for (int e = lane; e < 9 * D.nbody; e += RR_LANES) dg[D.g_xmat + e] = w.s_xmat[e];
-      for (int e = lane; e < 10 * D.nbody; e += RR_LANES) { dg[D.g_cinert + e] = w.s_cinert[e]; dg[D.g_crb + e] = w.s_crb[e]; }
-      for (int e = lane; e < 6 * D.nv; e += RR_LANES) dg[D.g_cdof + e] = w.s_cdof[e];
-      for (int e = lane; e < 6 * D.nbody; e += RR_LANES) { dg[D.g_cvel + e] = w.s_cvel[e]; dg[D.g_cfrc + e] = w.s_cfrc[e]; }
+    if (dg) {
       for (int e = lane; e < D.nM; e += RR_LANES) { dg[D.g_qM + e] = w.s_qM[e]; dg[D.g_qLD + e] = w.s_qLD[e]; }
-      if (lane == 0) { for (int k = 0; k < 3; ++k) { dg[D.g_com + k] = w.com0[k]; dg[D.g_com + 3 + k] = w.com1[k]; } }
 #pragma unroll
       for (int s = 0; s < NVS; ++s) {
         const int d = lane + RR_LANES * s;
@@ -1245,7 +1292,7 @@ __global__ __launch_bounds__(RR_LANES) void rr_step_kernel(const RRDims D, const
         }
       }
     }
-    w.constraints(dg);
+    w.constraint_rows(dg);
     w.template stamp<PROF>(7);
     niter = w.template solve<PROF>();
     w.template stamp<PROF>(12);
@@ -1255,7 +1302,6 @@ __global__ __launch_bounds__(RR_LANES) void rr_step_kernel(const RRDims D, const
         const int d = lane + RR_LANES * s;
         if (d < D.nv) { dg[D.g_qacc + d] = w.qacc[s]; dg[D.g_qfrc_constraint + d] = w.qfrc_con[s]; }
       }
-      for (int e = lane; e < D.nJ; e += RR_LANES) dg[D.g_J + e] = w.s_J[e];
       if (lane == 0) { dg[D.g_misc] = (float)niter; dg[D.g_misc + 1] = w.cost; }
     }
     if (io.mode & 1) w.euler();
@@ -1276,11 +1322,6 @@ __global__ __launch_bounds__(RR_LANES) void rr_step_kernel(const RRDims D, const
       if (io.o_qfrc_actuator) io.o_qfrc_actuator[(size_t)env * D.nv + d] = w.qfrc_actuator[s];
     }
   }
-  if (io.o_cinert) for (int e = lane; e < 10 * D.nbody; e += RR_LANES) io.o_cinert[(size_t)env * 10 * D.nbody + e] = w.s_cinert[e];
-  if (io.o_cvel) for (int e = lane; e < 6 * D.nbody; e += RR_LANES) io.o_cvel[(size_t)env * 6 * D.nbody + e] = w.s_cvel[e];
-  if (io.o_xpos) for (int e = lane; e < 3 * D.nbody; e += RR_LANES) io.o_xpos[(size_t)env * 3 * D.nbody + e] = w.s_xpos[e];
-  if (io.o_xmat) for (int e = lane; e < 9 * D.nbody; e += RR_LANES) io.o_xmat[(size_t)env * 9 * D.nbody + e] = w.s_xmat[e];
-  if (io.o_com && lane == 0) for (int k = 0; k < 3; ++k) io.o_com[(size_t)env * 3 + k] = w.com0[k];
 
   // ---- reference env epilogue [REF Rodent_Env_Brax.py:103-158]
   if (io.obs) {
@@ -1293,10 +1334,7 @@ __global__ __launch_bounds__(RR_LANES) void rr_step_kernel(const RRDims D, const
     o += D.nq;
     for (int i = lane; i < D.nv; i += RR_LANES) ob[o + i] = w.s_qvel[i];
     o += D.nv;
-    for (int i = lane; i < 10 * (D.nbody - 1); i += RR_LANES) ob[o + i] = w.s_cinert[10 + i];
-    o += 10 * (D.nbody - 1);
-    for (int i = lane; i < 6 * (D.nbody - 1); i += RR_LANES) ob[o + i] = w.s_cvel[6 + i];
-    o += 6 * (D.nbody - 1);
+    o += 16 * (D.nbody - 1);   // cinert[1:], cvel[1:] were written right after the last forward pass
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
       const int d = lane + RR_LANES * s;
@@ -1307,7 +1345,9 @@ __global__ __launch_bounds__(RR_LANES) void rr_step_kernel(const RRDims D, const
       int fi = new_frame + 1;
       fi = fi < 0 ? 0 : (fi > io.track_len - 1 ? io.track_len - 1 : fi);
       const v3 v = ld3(io.track_pos + 3 * fi) - ld3(w.s_qpos);
-      const float* xm = w.s_xmat + 9 + 3 * lane;
+      float m1[9];
+      quat_to_mat(m1, xq1);
+      const float* xm = m1 + 3 * lane;
       ob[o + lane] = xm[0] * v.x + xm[1] * v.y + xm[2] * v.z;
     }
     if (!is_reset) {
