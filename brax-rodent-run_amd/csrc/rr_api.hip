@@ -103,8 +103,8 @@ extern "C" int rr_model_load(const char* path, rr_model** out) {
   }
   static const char* need[] = {"nq", "nv", "nu", "nbody", "njnt", "ngeom", "nM", "ncon", "nlimit", "nefc", "obs_dim", "k_slots",
                                "k_lvl_adr", "k_lvl_body", "k_child", "k_body_i", "k_body_f", "k_jnt_i", "k_jnt_f", "k_dof_i",
-                               "k_dof_f", "k_act_f", "k_M_ij", "k_M_rowadr", "k_tri", "k_mulm", "k_solve_fwd", "k_solve_bwd",
-                               "k_solve_bwd_adr", "k_solve_bwd_level", "k_bwd_steps", "k_solve2", "k_solve_seq", "k_factor2", "k_factor2_first", "k_factor2_rows", "k_con_chain_packed", "k_con_i", "k_con_f", "k_con_chain", "k_jtf", "k_root_mass", "con_jadr",
+                               "k_dof_f", "k_act_f", "k_M_ij_k", "k_M_rowadr", "k_tri", "k_mulm", "k_solve_fwd", "k_solve_bwd",
+                               "k_solve_bwd_adr", "k_solve_bwd_level", "k_bwd_steps", "k_body_anc", "k_nround", "k_con_chain_bytes", "k_solve2", "k_solve_seq", "k_factor2", "k_factor2_first", "k_factor2_rows", "k_con_i", "k_con_f", "k_con_chain", "k_jtf", "k_root_mass", "con_jadr",
                                "dof_depth", "body_depth", "opt_timestep", "opt_gravity", "stat_meaninertia"};
   for (const char* nme : need)
     if (!m->find(nme)) { std::string s = std::string("rr_model_load: blob lacks '") + nme + "'"; delete m; return fail(RR_EIO, s); }
@@ -128,6 +128,10 @@ extern "C" int rr_model_load(const char* path, rr_model** out) {
   k.nroot = (int)m->find("k_root_mass")->count;
   k.ntri = (int)m->find("k_tri")->count;
   k.nbwd = (int)m->find("k_bwd_steps")->count;
+  k.nround = m->iscalar("k_nround");
+  if (d.nM > RR_LANES * (m->NVS == 1 ? 10 : (m->NVS == 2 ? 18 : 35))) { delete m; return fail(RR_EUNSUPPORTED, "rr_model_load: more mass-matrix entries than the kernel's register table"); }
+  k.nchain = (int)m->find("k_con_chain_bytes")->count;
+  k.nment = (d.nM + RR_LANES - 1) / RR_LANES;
   k.nfac = m->iscalar("k_factor2_rows");
   if (m->find("k_solve2")->dims[1] != m->NVS * RR_LANES) { delete m; return fail(RR_EUNSUPPORTED, "rr_model_load: level-solve table wider than the kernel instance"); }
   k.T_mulm = m->find("k_mulm")->dims[0]; k.T_jtf = m->find("k_jtf")->dims[0]; k.T_chain = m->find("k_con_chain")->dims[0];
@@ -138,10 +142,6 @@ extern "C" int rr_model_load(const char* path, rr_model** out) {
   if (k.nroot > 2) { delete m; return fail(RR_EUNSUPPORTED, "rr_model_load: more than 2 kinematic trees"); }
   if (m->find("k_dof_i")->dims[1] != RR_DOFI) { delete m; return fail(RR_EIO, "rr_model_load: k_dof_i width mismatch (stale blob)"); }
   if (m->find("k_body_i")->dims[1] != RR_BODYI) { delete m; return fail(RR_EIO, "rr_model_load: k_body_i width mismatch (stale blob)"); }
-  {
-    const int nme = m->NVS == 1 ? 10 : (m->NVS == 2 ? 18 : 35);
-    if (d.nM > RR_LANES * nme || k.nbwd > 2 * RR_LANES) { delete m; return fail(RR_EUNSUPPORTED, "rr_model_load: mass-matrix entries / tree schedule exceed the kernel's register tables"); }
-  }
   if (d.nv > 256 || d.ncon > 256) { delete m; return fail(RR_EUNSUPPORTED, "rr_model_load: nv/ncon above the 8-bit table index"); }
   if (m->find("k_mulm")->dims[1] != m->NVS * RR_LANES || m->find("k_con_chain")->dims[1] != m->NCS * RR_LANES) {
     delete m; return fail(RR_EIO, "rr_model_load: lane-table width mismatch");
@@ -180,15 +180,15 @@ struct rr_batch {
   unsigned long long* prof = nullptr;   // diagnostic phase-cycle buffer (rr_batch_set_profile)
 };
 
-template <typename Tp>
-static int upload(rr_batch* b, const char* name, const Tp** dst) {
+template <typename Ptr>
+static int upload(rr_batch* b, const char* name, Ptr* dst) {
   const Entry* e = b->m->find(name);
   void* p = nullptr;
   size_t bytes = std::max<size_t>(e->count, 1) * 4;
   HIPCHK(hipMalloc(&p, bytes));
   b->dev_allocs.push_back(p);
   if (e->count) HIPCHK(hipMemcpy(p, e->data, e->count * 4, hipMemcpyHostToDevice));
-  *dst = (const Tp*)p;
+  *dst = (Ptr)p;
   return RR_OK;
 }
 
@@ -210,8 +210,8 @@ extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t devi
   int rc = 0;
 #define UP(field, name) if ((rc = upload(b, name, &b->T.field))) { rr_batch_destroy(b); return rc; }
   UP(lvl_adr, "k_lvl_adr") UP(lvl_body, "k_lvl_body") UP(child, "k_child") UP(body_i, "k_body_i") UP(jnt_i, "k_jnt_i")
-  UP(dof_i, "k_dof_i") UP(M_ij, "k_M_ij") UP(M_rowadr, "k_M_rowadr") UP(tri, "k_tri") UP(mulm, "k_mulm")
-  UP(solve_fwd, "k_solve_fwd") UP(solve_bwd, "k_solve_bwd") UP(solve_bwd_adr, "k_solve_bwd_adr") UP(solve_bwd_level, "k_solve_bwd_level") UP(bwd_steps, "k_bwd_steps") UP(solve2, "k_solve2") UP(solve_seq, "k_solve_seq") UP(factor2, "k_factor2") UP(factor2_first, "k_factor2_first") UP(con_chain_packed, "k_con_chain_packed") UP(con_i, "k_con_i")
+  UP(dof_i, "k_dof_i") UP(M_ij_k, "k_M_ij_k") UP(M_rowadr, "k_M_rowadr") UP(tri, "k_tri") UP(mulm, "k_mulm")
+  UP(solve_fwd, "k_solve_fwd") UP(solve_bwd, "k_solve_bwd") UP(solve_bwd_adr, "k_solve_bwd_adr") UP(solve_bwd_level, "k_solve_bwd_level") UP(bwd_steps, "k_bwd_steps") UP(body_anc, "k_body_anc") UP(con_chain_packed, "k_con_chain_packed") UP(solve2, "k_solve2") UP(solve_seq, "k_solve_seq") UP(factor2, "k_factor2") UP(factor2_first, "k_factor2_first")  UP(con_i, "k_con_i")
   UP(con_chain, "k_con_chain") UP(jtf, "k_jtf") UP(body_f, "k_body_f") UP(jnt_f, "k_jnt_f") UP(dof_f, "k_dof_f")
   UP(act_f, "k_act_f") UP(con_f, "k_con_f") UP(root_mass, "k_root_mass")
 #undef UP

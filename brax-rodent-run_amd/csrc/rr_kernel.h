@@ -22,27 +22,38 @@
 #define RR_PF 4      // table rows kept in flight by the level-parallel factor / solve loops
 #define RR_U 8       // lane tables are consumed in batches of RR_U rows: their loads are issued together
 #define RR_NPH 16    // phases of the diagnostic (s_memtime) build
+#ifndef RR_EXP
+#define RR_EXP 0
+#endif
+#if RR_EXP == 1
+#define RR_SOLVE_ADD(p, v) (*(p) = (v))      /* timing experiment: plain store instead of the LDS atomic */
+#else
+#define RR_SOLVE_ADD(p, v) atomicAdd((p), (v))
+#endif
 #define RR_MINVAL 1e-15f
 #define RR_MINIMP 0.0001f
 #define RR_MAXIMP 0.9999f
 
 struct RRDims {
   int nq, nv, nu, nbody, njnt, nM, ncon, nlevel, dmax, nroot;
-  int T_mulm, T_jtf, T_chain, obs_dim, iterations, ls_iterations, nJ, ntri, nbwd, nfac;
+  int T_mulm, T_jtf, T_chain, obs_dim, iterations, ls_iterations, nJ, ntri, nbwd, nfac, nround, nchain, nment;
   float dt, gx, gy, gz, tolerance, ls_tolerance, meaninertia;
   // LDS offsets (floats)
   int o_qpos, o_qvel, o_act, o_ctrl, o_xpos, o_xquat, o_cinert, o_cdof, o_cvel,
-      o_qM, o_qLD, o_vec, o_x, o_y, o_arm, lds_floats;
+      o_qM, o_qLD, o_vec, o_x, o_y, o_arm, o_chain, lds_floats;
   // debug dump offsets (floats)
   int g_xpos, g_xquat, g_xmat, g_com, g_cinert, g_crb, g_cdof, g_cvel, g_cfrc, g_qM, g_qLD, g_dinv, g_bias, g_passive,
       g_actuator, g_smooth, g_qacc_smooth, g_con_dist, g_con_pos, g_con_frame, g_con_D, g_con_aref, g_lim, g_qacc,
       g_qfrc_constraint, g_misc, g_J, dbg_floats;
 };
 
+// Table pointers carry the global address space in their type, so every table access is a global_load (never flat).
+typedef const int __attribute__((address_space(1)))* rr_gi;
+typedef const float __attribute__((address_space(1)))* rr_gf;
 struct RRTables {
-  const int *lvl_adr, *lvl_body, *child, *body_i, *jnt_i, *dof_i, *M_ij, *M_rowadr, *tri, *mulm, *solve_fwd, *solve_bwd,
-      *solve_bwd_adr, *solve_bwd_level, *bwd_steps, *con_chain_packed, *solve2, *solve_seq, *factor2, *factor2_first, *con_i, *con_chain, *jtf;
-  const float *body_f, *jnt_f, *dof_f, *act_f, *con_f, *root_mass;
+  rr_gi lvl_adr, lvl_body, child, body_i, jnt_i, dof_i, M_ij_k, M_rowadr, tri, mulm, solve_fwd, solve_bwd,
+      solve_bwd_adr, solve_bwd_level, bwd_steps, body_anc, con_chain_packed, solve2, solve_seq, factor2, factor2_first, con_i, con_chain, jtf;
+  rr_gf body_f, jnt_f, dof_f, act_f, con_f, root_mass;
 };
 
 struct RRIO {
@@ -64,6 +75,7 @@ struct RRIO {
 struct v3 { float x, y, z; };
 __device__ __forceinline__ v3 mk3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
 __device__ __forceinline__ v3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+__device__ __forceinline__ v3 ld3(const float __attribute__((address_space(1)))* p) { return mk3(p[0], p[1], p[2]); }
 __device__ __forceinline__ void st3(float* p, v3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
 __device__ __forceinline__ v3 operator+(v3 a, v3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
 __device__ __forceinline__ v3 operator-(v3 a, v3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
@@ -184,6 +196,10 @@ __device__ __forceinline__ void kbi(float dt, float sr0, float sr1, const float*
 
 struct LSPoint { float alpha, cost, d0, d1; };
 
+// Table loads in the hot loops must be GLOBAL loads: when the optimiser loses the address space of a table pointer it
+// emits flat_load, which also counts on lgkmcnt -- every LDS wait would then drain the table prefetch as well.
+__device__ __forceinline__ int g_int(const int __attribute__((address_space(1)))* base, int idx) { return base[idx]; }
+
 // Identity the optimiser cannot see through: stops loop-invariant code motion from unpacking every packed index
 // table entry once, ahead of the solver loops, and keeping hundreds of unpacked indices / addresses alive in
 // registers (the unpack is 2 VALU ops; the registers are what limits residency).
@@ -194,13 +210,13 @@ __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); retur
 struct BodyC {
   int parent, depth, sib, dofadr, dofnum, jn, jadr;
   int jtype0, jqa0, jda0;
-  float pos[3], quat[4], jpos0[3], jaxis0[3];
+  float pos[3], quat[4], jpos0[3], jaxis0[3], jq00;
 };
 __device__ __forceinline__ BodyC load_bodyc(const RRTables& T, int b, int nbody) {
   BodyC c;
   const bool ok = b >= 1 && b < nbody;
-  const int* bi = T.body_i + RR_BODYI * (ok ? b : 0);
-  const float* bf = T.body_f + 18 * (ok ? b : 0);
+  auto bi = T.body_i + RR_BODYI * (ok ? b : 0);
+  auto bf = T.body_f + 18 * (ok ? b : 0);
   c.parent = bi[0]; c.jadr = bi[1]; c.jn = ok ? bi[2] : 0; c.dofadr = bi[3]; c.dofnum = bi[4];
   c.depth = ok ? bi[8] : -1; c.sib = bi[9];
 #pragma unroll
@@ -208,11 +224,12 @@ __device__ __forceinline__ BodyC load_bodyc(const RRTables& T, int b, int nbody)
 #pragma unroll
   for (int k = 0; k < 4; ++k) c.quat[k] = bf[3 + k];
   const int j = c.jn > 0 ? c.jadr : 0;
-  const int* ji = T.jnt_i + 4 * j;
-  const float* jf = T.jnt_f + 8 * j;
+  auto ji = T.jnt_i + 4 * j;
+  auto jf = T.jnt_f + 8 * j;
   c.jtype0 = c.jn > 0 ? ji[0] : 3; c.jqa0 = ji[1]; c.jda0 = ji[2];
 #pragma unroll
   for (int k = 0; k < 3; ++k) { c.jpos0[k] = jf[k]; c.jaxis0[k] = jf[3 + k]; }
+  c.jq00 = jf[6];
   return c;
 }
 
@@ -228,20 +245,19 @@ struct Wave {
   // s_buf reuses xpos|xquat after the contact geometry has been taken.
   float *s_qpos, *s_qvel, *s_act, *s_ctrl, *s_xpos, *s_xquat, *s_cinert, *s_crb, *s_cdof, *s_cvel, *s_cacc,
       *s_cfrc, *s_buf, *s_sc, *s_qM, *s_qLD, *s_vec, *s_x, *s_y, *s_arm;
+
   static constexpr int W = NVS * RR_LANES;
   static constexpr int WC = NCS * RR_LANES;
 
   // ---- model constants held in registers for the whole launch (loaded once, reused by all substeps)
   BodyC bc0;              // constants of body `lane` (slot 0)
-  int bdepth[NBS], bsib[NBS];   // depth / sibling rank of every slot's body (schedule predicates)
-  int dofbody[NVS], dofkind[NVS], dofroot[NVS], dofqadr[NVS];
-  float dofq0[NVS];
+  int banc[NBS][2];       // 2^k-th ancestors of the slot's body, k = 0..7, one byte each (0 = none)
+  int blast[NBS];         // last body of the subtree (bodies are in DFS order)
   static constexpr int NME = NVS == 1 ? 10 : (NVS == 2 ? 18 : 35);   // sparse-M entries per lane (nM <= 64*NME)
   int ment[NME];          // entry e = lane + 64*it of qM: row i | col j << 8, -1 beyond nM
-  int bwd_step_r[2];      // backward-sweep schedule (level | sibling rank << 8), lane st holds step st
+  int dofc0[NVS], dofc1[NVS];   // packed per-dof constants: depth | kind<<8 | root<<12 | body<<16 | parent-of-body<<24 ; Madr | last_desc<<16
   int con_chain[NCS][9];  // ancestor dof chain of the contact's body, leaf first, 4 dof ids per register
   // per-dof registers (slot s -> dof lane + 64 s)
-  int dofdepth[NVS], dofmadr[NVS], doflast[NVS];
   float dinv[NVS];
   float qfrc_smooth[NVS], qfrc_actuator[NVS], qacc_smooth[NVS], act_dot[NVS];
   float qacc[NVS], Ma[NVS], grad[NVS], Mgrad[NVS], search[NVS], mv[NVS], qfrc_con[NVS], warm[NVS];
@@ -275,7 +291,11 @@ struct Wave {
   // compiler keeps the program order of the LDS accesses around this point.
   // "memory" keeps the compiler from moving LDS accesses across; lgkmcnt(0) retires this wave's LDS operations
   // (incl. the float atomics) without draining outstanding global table prefetches (no vmcnt wait).
+#if RR_EXP == 2
+  __device__ __forceinline__ void sync() { asm volatile("" ::: "memory"); }   /* timing experiment: no LDS drain */
+#else
   __device__ __forceinline__ void sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+#endif
   __device__ __forceinline__ v3 get_com(int r) const {
     return mk3(r ? com1[0] : com0[0], r ? com1[1] : com0[1], r ? com1[2] : com0[2]);
   }
@@ -284,87 +304,109 @@ struct Wave {
   // wave-uniform predicate -> scalar branch
   static __device__ __forceinline__ bool uni(bool p) { return __builtin_amdgcn_readfirstlane((int)p) != 0; }
 
-  // ---------------------------------------------------------------- A-1 kinematics (level sweep)
-  // Lane b owns body b for every level; its constants are in registers, so a level costs only the
-  // LDS hand-off of the parent's (pos, quat).  Rotation matrices are rebuilt from the quaternion where needed
-  // (xmat is not stored: LDS budget).
+  // ---------------------------------------------------------------- A-1 kinematics (pointer doubling)
+  // Every body first builds its LOCAL transform (parent frame -> body, all joints applied) in parallel; world
+  // poses are then the prefix products along the tree, formed in ceil(log2(depth)) pointer-doubling rounds
+  // T[b] <- T[anc_k(b)] o T[b], anc_{k+1} = anc_k o anc_k (ancestor tables in registers), all bodies busy every
+  // round, instead of one serial step per tree level (38-39 of them, a handful of active lanes each).
+  // Joint anchors / axes are kept in the parent frame (raw, in the cdof cells) and mapped to the world in com_pos.
+  __device__ __forceinline__ BodyC bodyc(int s) const { return s == 0 ? bc0 : load_bodyc(T, lane + RR_LANES * s, D.nbody); }
+  __device__ __forceinline__ int anc_at(int s, int k) const { return (opaque(banc[s][k >> 2]) >> (8 * (k & 3))) & 255; }
+
   __device__ __forceinline__ void kinematics() {
-    // half-angle sin / cos of every hinge, one joint per lane, before the serial level sweep
 #pragma unroll
-    for (int s = 0; s < NVS; ++s) {
-      const int d = lane + RR_LANES * s;
-      if (d < D.nv && dofkind[s] == 6) {
-        const float ang = s_qpos[dofqadr[s]] - dofq0[s];
-        s_sc[2 * d] = sinf(ang * 0.5f);
-        s_sc[2 * d + 1] = cosf(ang * 0.5f);
+    for (int s = 0; s < NBS; ++s) {
+      const int b = lane + RR_LANES * s;
+      if (s > 0 && !__any(b < D.nbody)) continue;
+      const BodyC c = bodyc(s);
+      if (b >= 1 && b < D.nbody) {
+        float quat[4], mat[9];
+        v3 pos = mk3(c.pos[0], c.pos[1], c.pos[2]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) quat[k] = c.quat[k];
+        for (int jj = 0; jj < c.jn; ++jj) {
+          int jt, qa, da;
+          v3 jp, ja;
+          float q0;
+          if (jj == 0) {
+            jt = c.jtype0; qa = c.jqa0; da = c.jda0; q0 = c.jq00;
+            jp = mk3(c.jpos0[0], c.jpos0[1], c.jpos0[2]); ja = mk3(c.jaxis0[0], c.jaxis0[1], c.jaxis0[2]);
+          } else {   // 2nd / 3rd joint of a multi-joint body: parameters from the tables
+            auto ji = T.jnt_i + 4 * (c.jadr + jj);
+            auto jf = T.jnt_f + 8 * (c.jadr + jj);
+            jt = ji[0]; qa = ji[1]; da = ji[2]; q0 = jf[6];
+            jp = ld3(jf); ja = ld3(jf + 3);
+          }
+          if (jt == 0) {  // free joint: the pose is the generalised coordinate itself (parent = world)
+            pos = ld3(s_qpos + qa);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) quat[k] = s_qpos[qa + 3 + k];
+            quat_normalize(quat);
+          } else {  // hinge
+            quat_to_mat(mat, quat);
+            const v3 anchor = mat_vec(mat, jp) + pos;
+            const v3 axis = mat_vec(mat, ja);
+            st3(s_cdof + 6 * da, axis);        // raw, parent frame: axis ; anchor
+            st3(s_cdof + 6 * da + 3, anchor);
+            const float ang = (s_qpos[qa] - q0) * 0.5f;
+            const float sn = sinf(ang), cs = cosf(ang);
+            float ql[4] = {cs, ja.x * sn, ja.y * sn, ja.z * sn}, qn[4];
+            quat_mul(qn, quat, ql);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) quat[k] = qn[k];
+            quat_to_mat(mat, quat);
+            pos = anchor - mat_vec(mat, jp);
+          }
+        }
+        st3(s_xpos + 3 * b, pos);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_xquat[4 * b + k] = quat[k];
       }
     }
     sync();
-    for (int L = 1; L <= D.nlevel; ++L) {
+    for (int k = 0; k < D.nround; ++k) {
+      float np[NBS][3], nq[NBS][4];
+      bool upd[NBS];
 #pragma unroll
       for (int s = 0; s < NBS; ++s) {
-        const bool on = bdepth[s] == L;
-        if (__any(on)) {
-          const BodyC c = s == 0 ? bc0 : load_bodyc(T, lane + RR_LANES * s, D.nbody);
-          if (on) {
-            const int b = lane + RR_LANES * s, p = c.parent;
-            float quat[4], mat[9], pq[4];
+        const int b = lane + RR_LANES * s;
+        const int a = anc_at(s, k);
+        upd[s] = b >= 1 && b < D.nbody && a != 0;
+        if (upd[s]) {
+          float qa_[4], qb[4], mat[9];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) pq[k] = s_xquat[4 * p + k];
-            quat_to_mat(mat, pq);
-            v3 pos = ld3(s_xpos + 3 * p) + mat_vec(mat, mk3(c.pos[0], c.pos[1], c.pos[2]));
-            quat_mul(quat, pq, c.quat);
-            int free_da = -1;
-            for (int jj = 0; jj < c.jn; ++jj) {
-              int jt, qa, da;
-              v3 jp, ja;
-              if (jj == 0) {
-                jt = c.jtype0; qa = c.jqa0; da = c.jda0;
-                jp = mk3(c.jpos0[0], c.jpos0[1], c.jpos0[2]); ja = mk3(c.jaxis0[0], c.jaxis0[1], c.jaxis0[2]);
-              } else {   // 2nd / 3rd joint of a multi-joint body: parameters from the tables
-                const int* ji = T.jnt_i + 4 * (c.jadr + jj);
-                const float* jf = T.jnt_f + 8 * (c.jadr + jj);
-                jt = ji[0]; qa = ji[1]; da = ji[2];
-                jp = ld3(jf); ja = ld3(jf + 3);
-              }
-              if (jt == 0) {  // free
-                pos = ld3(s_qpos + qa);
+          for (int i = 0; i < 4; ++i) { qa_[i] = s_xquat[4 * a + i]; qb[i] = s_xquat[4 * b + i]; }
+          quat_to_mat(mat, qa_);
+          const v3 p = ld3(s_xpos + 3 * a) + mat_vec(mat, ld3(s_xpos + 3 * b));
+          np[s][0] = p.x; np[s][1] = p.y; np[s][2] = p.z;
+          quat_mul(nq[s], qa_, qb);
+        }
+      }
+      sync();
 #pragma unroll
-                for (int k = 0; k < 4; ++k) quat[k] = s_qpos[qa + 3 + k];
-                quat_normalize(quat);
-                free_da = da;
-              } else {  // hinge
-                quat_to_mat(mat, quat);
-                const v3 anchor = mat_vec(mat, jp) + pos;
-                const v3 axis = mat_vec(mat, ja);
-                st3(s_cdof + 6 * da, axis);        // raw: axis ; anchor (finalised in com_pos)
-                st3(s_cdof + 6 * da + 3, anchor);
-                const float sn = s_sc[2 * da], cs = s_sc[2 * da + 1];
-                float ql[4] = {cs, ja.x * sn, ja.y * sn, ja.z * sn}, qn[4];
-                quat_mul(qn, quat, ql);
+      for (int s = 0; s < NBS; ++s) {
+        if (upd[s]) {
+          const int b = lane + RR_LANES * s;
+          st3(s_xpos + 3 * b, mk3(np[s][0], np[s][1], np[s][2]));
 #pragma unroll
-                for (int k = 0; k < 4; ++k) quat[k] = qn[k];
-                quat_to_mat(mat, quat);
-                pos = anchor - mat_vec(mat, jp);
-              }
-            }
-            quat_normalize(quat);
-            st3(s_xpos + 3 * b, pos);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) s_xquat[4 * b + k] = quat[k];
-            if (free_da >= 0) {
-              quat_to_mat(mat, quat);
-#pragma unroll
-              for (int k = 0; k < 3; ++k) {
-                st3(s_cdof + 6 * (free_da + 3 + k), mk3(mat[k], mat[3 + k], mat[6 + k]));
-                st3(s_cdof + 6 * (free_da + 3 + k) + 3, pos);
-              }
-            }
-          }
+          for (int i = 0; i < 4; ++i) s_xquat[4 * b + i] = nq[s][i];
         }
       }
       sync();
     }
+#pragma unroll
+    for (int s = 0; s < NBS; ++s) {   // xquat is kept normalised, as the reference does per body
+      const int b = lane + RR_LANES * s;
+      if (b >= 1 && b < D.nbody) {
+        float q[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = s_xquat[4 * b + i];
+        quat_normalize(q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s_xquat[4 * b + i] = q[i];
+      }
+    }
+    sync();
   }
 
   // ---------------------------------------------------------------- A-2 com_pos: subtree COM per root, cinert, cdof
@@ -376,7 +418,7 @@ struct Wave {
       const int b = lane + RR_LANES * s;
       xip[s][0] = xip[s][1] = xip[s][2] = 0;
       if (b >= 1 && b < D.nbody) {
-        const float* bf = T.body_f + 18 * b;
+        auto bf = T.body_f + 18 * b;
         float bq[4], R[9];
 #pragma unroll
         for (int k = 0; k < 4; ++k) bq[k] = s_xquat[4 * b + k];
@@ -397,7 +439,7 @@ struct Wave {
     for (int s = 0; s < NBS; ++s) {
       const int b = lane + RR_LANES * s;
       if (b >= 1 && b < D.nbody) {
-        const float* bf = T.body_f + 18 * b;
+        auto bf = T.body_f + 18 * b;
         float q[4], bq[4], iq[4], R[9];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { bq[k] = s_xquat[4 * b + k]; iq[k] = bf[10 + k]; }
@@ -420,105 +462,178 @@ struct Wave {
         c[6] = mass * d0; c[7] = mass * d1; c[8] = mass * d2; c[9] = mass;
       }
     }
-    // cdof: finalise raw (axis; anchor) -> (axis; axis x (com - anchor))   [mju_dofCom]
+    // cdof [mju_dofCom]: hinge raw (axis; anchor) is in the parent frame of the joint's body -> world, then
+    // (axis; axis x (com - anchor)); free joint: translations along the world axes, rotations about the body axes
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
       const int d = lane + RR_LANES * s;
       if (d < D.nv) {
-        const int kind = dofkind[s];
+        const int kind = ((opaque(dofc0[s]) >> 8) & 15);
         float* c = s_cdof + 6 * d;
         if (kind < 3) {
           c[0] = c[1] = c[2] = 0;
           c[3] = kind == 0; c[4] = kind == 1; c[5] = kind == 2;
         } else {
-          v3 ax = ld3(c);
-          v3 off = get_com(dofroot[s]) - ld3(c + 3);
-          st3(c + 3, cross(ax, off));
+          const int fb = kind < 6 ? ((opaque(dofc0[s]) >> 16) & 255) : ((opaque(dofc0[s]) >> 24) & 255);     // frame the raw data is expressed in
+          float q[4], R[9];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) q[k] = s_xquat[4 * fb + k];
+          quat_to_mat(R, q);
+          v3 ax, anchor;
+          if (kind < 6) {
+            ax = mk3(R[kind - 3], R[3 + kind - 3], R[6 + kind - 3]);
+            anchor = ld3(s_xpos + 3 * fb);
+          } else {
+            ax = mat_vec(R, ld3(c));
+            anchor = ld3(s_xpos + 3 * fb) + mat_vec(R, ld3(c + 3));
+          }
+          st3(c, ax);
+          st3(c + 3, cross(ax, get_com(((opaque(dofc0[s]) >> 12) & 15)) - anchor));
         }
       }
     }
     sync();
   }
 
-  // ---------------------------------------------------------------- A-6 com_vel + rne forward part (level sweep)
-  __device__ __forceinline__ void velocity_sweep() {
-    for (int L = 1; L <= D.nlevel; ++L) {
+  // ---------------------------------------------------------------- A-6 com_vel + rne (prefix sums over the tree)
+  // cvel[b] = sum over the ancestor chain of each body's own sum(cdof * qvel): an inclusive tree prefix sum by the
+  // same pointer-doubling rounds as the kinematics; cdof_dot then needs only the parent's cvel (lane-local loop over
+  // the body's dofs), and cacc is a second prefix sum of sum(cdof_dot * qvel) on top of the world's -gravity.
+  __device__ __forceinline__ void tree_prefix6(float* arr) {
+    for (int k = 0; k < D.nround; ++k) {
+      float add[NBS][6];
+      bool upd[NBS];
 #pragma unroll
       for (int s = 0; s < NBS; ++s) {
-        const bool on = bdepth[s] == L;
-        if (__any(on)) {
-          const BodyC c = s == 0 ? bc0 : load_bodyc(T, lane + RR_LANES * s, D.nbody);
-          if (on) {
-            const int b = lane + RR_LANES * s, p = c.parent, da = c.dofadr, dn = c.dofnum;
-            float v[6], a[6];
+        const int b = lane + RR_LANES * s;
+        const int a = anc_at(s, k);
+        upd[s] = b >= 1 && b < D.nbody && a != 0;
+        if (upd[s]) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) { v[k] = s_cvel[6 * p + k]; a[k] = s_cacc[6 * p + k]; }
-            const bool is_free = c.jn > 0 && c.jtype0 == 0;
-            if (is_free) {
-              for (int k = 0; k < 3; ++k) {
-                const float qv = s_qvel[da + k];
-                for (int i = 0; i < 6; ++i) v[i] += s_cdof[6 * (da + k) + i] * qv;
-              }
-              float cd[3][6];
-              for (int k = 0; k < 3; ++k) cross_motion(cd[k], v, s_cdof + 6 * (da + 3 + k));
-              for (int k = 0; k < 3; ++k) {
-                const float qv = s_qvel[da + 3 + k];
-                for (int i = 0; i < 6; ++i) v[i] += s_cdof[6 * (da + 3 + k) + i] * qv;
-              }
-              for (int k = 0; k < 3; ++k) {
-                const float qv = s_qvel[da + 3 + k];
-                for (int i = 0; i < 6; ++i) a[i] += cd[k][i] * qv;
-              }
-            } else {
-              for (int k = 0; k < dn; ++k) {
-                float cd[6];
-                cross_motion(cd, v, s_cdof + 6 * (da + k));
-                const float qv = s_qvel[da + k];
-                for (int i = 0; i < 6; ++i) { v[i] += s_cdof[6 * (da + k) + i] * qv; a[i] += cd[i] * qv; }
-              }
-            }
-            float t[6], t1[6], t2[6];
-            mul_inert_vec(t, s_cinert + 10 * b, v);
-            cross_force(t1, v, t);
-            mul_inert_vec(t2, s_cinert + 10 * b, a);
+          for (int i = 0; i < 6; ++i) add[s][i] = arr[6 * a + i];
+        }
+      }
+      sync();
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-              s_cvel[6 * b + k] = v[k];
-              s_cacc[6 * b + k] = a[k];
-              s_cfrc[6 * b + k] = t2[k] + t1[k];
-            }
-          }
+      for (int s = 0; s < NBS; ++s) {
+        if (upd[s]) {
+          const int b = lane + RR_LANES * s;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) arr[6 * b + i] += add[s][i];
         }
       }
       sync();
     }
   }
 
-  // ---------------------------------------------------------------- crb + cfrc backward accumulation
-  // Scheduled by (level, sibling rank): at each step every selected body adds itself into its parent;
-  // siblings take turns (largest id first = the reference's accumulation order), so no two lanes touch
-  // the same parent in one step.
-  __device__ __forceinline__ void backward_sweep() {
-    // composite inertia accumulates IN PLACE in the cinert region (cinert itself has been consumed / written out)
-    for (int st = 0; st < D.nbwd; ++st) {
-      const int code = st < RR_LANES ? __builtin_amdgcn_readlane(bwd_step_r[0], st & 63) : __builtin_amdgcn_readlane(bwd_step_r[1], st & 63);
-      const int L = code & 255, r = code >> 8;
+  __device__ __forceinline__ void velocity_sweep() {
+    // own contribution of every body
 #pragma unroll
-      for (int s = 0; s < NBS; ++s) {
-        const bool on = bdepth[s] == L && bsib[s] == r;
-        if (__any(on)) {
-          const int pp = s == 0 ? bc0.parent : T.body_i[RR_BODYI * min(lane + RR_LANES * s, D.nbody - 1)];
-          if (on) {
-            const int b = lane + RR_LANES * s, p = pp;
+    for (int s = 0; s < NBS; ++s) {
+      const int b = lane + RR_LANES * s;
+      if (s > 0 && !__any(b < D.nbody)) continue;
+      const BodyC c = bodyc(s);
+      if (b >= 1 && b < D.nbody) {
+        float v[6] = {0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < c.dofnum; ++k) {
+          const float qv = s_qvel[c.dofadr + k];
 #pragma unroll
-            for (int k = 0; k < 10; ++k) s_crb[10 * p + k] += s_crb[10 * b + k];
+          for (int i = 0; i < 6; ++i) v[i] += s_cdof[6 * (c.dofadr + k) + i] * qv;
+        }
 #pragma unroll
-            for (int k = 0; k < 6; ++k) s_cfrc[6 * p + k] += s_cfrc[6 * b + k];
+        for (int i = 0; i < 6; ++i) s_cvel[6 * b + i] = v[i];
+      }
+    }
+    sync();
+    tree_prefix6(s_cvel);
+    // cdof_dot (lane-local) -> own acceleration contribution
+#pragma unroll
+    for (int s = 0; s < NBS; ++s) {
+      const int b = lane + RR_LANES * s;
+      if (s > 0 && !__any(b < D.nbody)) continue;
+      const BodyC c = bodyc(s);
+      if (b >= 1 && b < D.nbody) {
+        const int p = c.parent, da = c.dofadr, dn = c.dofnum;
+        float v[6], a[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v[k] = s_cvel[6 * p + k];
+        const bool is_free = c.jn > 0 && c.jtype0 == 0;
+        if (is_free) {
+          for (int k = 0; k < 3; ++k) {
+            const float qv = s_qvel[da + k];
+            for (int i = 0; i < 6; ++i) v[i] += s_cdof[6 * (da + k) + i] * qv;
+          }
+          for (int k = 0; k < 3; ++k) {   // all three rotational cdof_dot use the velocity after the translations
+            float cd[6];
+            cross_motion(cd, v, s_cdof + 6 * (da + 3 + k));
+            const float qv = s_qvel[da + 3 + k];
+            for (int i = 0; i < 6; ++i) a[i] += cd[i] * qv;
+          }
+        } else {
+          for (int k = 0; k < dn; ++k) {
+            float cd[6];
+            cross_motion(cd, v, s_cdof + 6 * (da + k));
+            const float qv = s_qvel[da + k];
+            for (int i = 0; i < 6; ++i) { v[i] += s_cdof[6 * (da + k) + i] * qv; a[i] += cd[i] * qv; }
           }
         }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s_cacc[6 * b + i] = a[i];
       }
-      sync();
     }
+    sync();
+    tree_prefix6(s_cacc);
+    // body forces: cfrc = I (cacc - g) + cvel x* (I cvel)
+#pragma unroll
+    for (int s = 0; s < NBS; ++s) {
+      const int b = lane + RR_LANES * s;
+      if (b >= 1 && b < D.nbody) {
+        float v[6], a[6], t[6], t1[6], t2[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { v[k] = s_cvel[6 * b + k]; a[k] = s_cacc[6 * b + k]; }
+        a[3] -= D.gx; a[4] -= D.gy; a[5] -= D.gz;
+        mul_inert_vec(t, s_cinert + 10 * b, v);
+        cross_force(t1, v, t);
+        mul_inert_vec(t2, s_cinert + 10 * b, a);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s_cfrc[6 * b + k] = t2[k] + t1[k];
+      }
+    }
+    sync();
+  }
+
+  // ---------------------------------------------------------------- crb + cfrc: subtree sums over DFS ranges
+  // Bodies are in depth-first order, so the subtree of b is the contiguous range [b, blast[b]]: every lane sums its
+  // own range straight from LDS (no level steps, no hand-offs), keeps the 16 sums in registers, and the results are
+  // written back in place after all reads.
+  __device__ __forceinline__ void backward_sweep() {
+    float acc[NBS][16];
+#pragma unroll
+    for (int s = 0; s < NBS; ++s) {
+      const int b = lane + RR_LANES * s;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[s][k] = 0.0f;
+      if (b >= 1 && b < D.nbody) {
+        for (int d = b; d <= blast[s]; ++d) {
+#pragma unroll
+          for (int k = 0; k < 10; ++k) acc[s][k] += s_cinert[10 * d + k];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) acc[s][10 + k] += s_cfrc[6 * d + k];
+        }
+      }
+    }
+    sync();
+#pragma unroll
+    for (int s = 0; s < NBS; ++s) {
+      const int b = lane + RR_LANES * s;
+      if (b >= 1 && b < D.nbody) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) s_crb[10 * b + k] = acc[s][k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s_cfrc[6 * b + k] = acc[s][10 + k];
+      }
+    }
+    sync();
   }
 
   // ---------------------------------------------------------------- A-3 qM (sparse) from crb and cdof
@@ -526,7 +641,7 @@ struct Wave {
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
       const int d = lane + RR_LANES * s;
-      if (d < D.nv) mul_inert_vec(s_buf + 6 * d, s_crb + 10 * dofbody[s], s_cdof + 6 * d);
+      if (d < D.nv) mul_inert_vec(s_buf + 6 * d, s_crb + 10 * ((opaque(dofc0[s]) >> 16) & 255), s_cdof + 6 * d);
     }
     sync();
 #pragma unroll
@@ -554,23 +669,24 @@ struct Wave {
 #pragma unroll
       for (int s = 0; s < NVS; ++s) {
         const int d = lane + RR_LANES * s;
-        if (d < D.nv) s_qLD[dofmadr[s]] += damp * T.dof_f[16 * d + 1];
+        if (d < D.nv) s_qLD[(opaque(dofc1[s]) & 0xFFFF)] += damp * T.dof_f[16 * d + 1];
       }
       sync();
     }
     // rows are padded to a multiple of RR_PF; a ring of RR_PF rows is kept in flight so the L2 latency of the
     // table stream is hidden behind RR_PF-1 rows of LDS work
-    const int2* tab = reinterpret_cast<const int2*>(T.factor2);
+    typedef const unsigned long long __attribute__((address_space(1)))* rr_gu64;
+    rr_gu64 tab = (rr_gu64)T.factor2;
     int2 ring[RR_PF];
     int fring[RR_PF];
 #pragma unroll
-    for (int u = 0; u < RR_PF; ++u) { ring[u] = tab[u * RR_LANES + lane]; fring[u] = T.factor2_first[u]; }
+    for (int u = 0; u < RR_PF; ++u) { { const unsigned long long q_ = tab[u * RR_LANES + lane]; ring[u].x = (int)(unsigned)q_; ring[u].y = (int)(q_ >> 32); } fring[u] = g_int(T.factor2_first, u); }
     for (int r0 = 0; r0 < D.nfac; r0 += RR_PF) {
 #pragma unroll
       for (int u = 0; u < RR_PF; ++u) {
         const int2 e = ring[u];
         const int first = fring[u];
-        if (r0 + RR_PF < D.nfac) { ring[u] = tab[(r0 + RR_PF + u) * RR_LANES + lane]; fring[u] = T.factor2_first[r0 + RR_PF + u]; }
+        if (r0 + RR_PF < D.nfac) { { const unsigned long long q_ = tab[(r0 + RR_PF + u) * RR_LANES + lane]; ring[u].x = (int)(unsigned)q_; ring[u].y = (int)(q_ >> 32); } fring[u] = g_int(T.factor2_first, r0 + RR_PF + u); }
         if (first) sync();     // updates of the deeper level must have landed
         if (e.x >= 0) {
           const int a = e.x & 4095, bq = e.x >> 12, dst = e.y & 4095, piv = e.y >> 12;
@@ -583,7 +699,7 @@ struct Wave {
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
       const int d = lane + RR_LANES * s;
-      dinv[s] = d < D.nv ? 1.0f / s_qLD[dofmadr[s]] : 0.0f;
+      dinv[s] = d < D.nv ? 1.0f / s_qLD[(opaque(dofc1[s]) & 0xFFFF)] : 0.0f;
       if (d < D.nv) s_arm[D.nv + d] = dinv[s];   // s_arm[nv..2nv): 1/D per dof for the row scaling below
     }
     sync();
@@ -606,43 +722,39 @@ struct Wave {
     constexpr int W2 = NVS * RR_LANES;
 #pragma unroll
     for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; if (d < D.nv) s_x[d] = x[s]; }
-    // k_solve_seq: dmax backward rows (deep -> shallow), then dmax forward rows (shallow -> deep), padded to RR_PF
-    int ring[RR_PF][NVS];
+    // k_solve_seq: dmax backward rows (deep -> shallow), then dmax forward rows (shallow -> deep).  Slots beyond the
+    // first hold entries only at the few levels with more than 64 of them: skipped by a wave-uniform test.
+    auto tab = T.solve_seq;
+    int en[NVS];
 #pragma unroll
-    for (int u = 0; u < RR_PF; ++u)
-#pragma unroll
-      for (int s = 0; s < NVS; ++s) ring[u][s] = T.solve_seq[u * W2 + s * RR_LANES + lane];
+    for (int s = 0; s < NVS; ++s) en[s] = g_int(tab, s * RR_LANES + lane);
     sync();
-    const int nrow = 2 * D.dmax;
-    for (int r0 = 0; r0 < nrow; r0 += RR_PF) {
+    for (int r = 0; r < D.dmax; ++r) {           // backward pass (L^-T): x_j -= L_ij x_i
+      int e[NVS];
 #pragma unroll
-      for (int u = 0; u < RR_PF; ++u) {
-        const int r = r0 + u;
-        int e[NVS];
+      for (int s = 0; s < NVS; ++s) { e[s] = en[s]; en[s] = g_int(tab, (r + 1) * W2 + s * RR_LANES + lane); }
 #pragma unroll
-        for (int s = 0; s < NVS; ++s) e[s] = ring[u][s];
-        if (r0 + RR_PF < nrow) {
-#pragma unroll
-          for (int s = 0; s < NVS; ++s) ring[u][s] = T.solve_seq[(r + RR_PF) * W2 + s * RR_LANES + lane];
-        }
-        if (r == D.dmax) {   // between the passes: x <- D^-1 x
-#pragma unroll
-          for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; if (d < D.nv) s_x[d] *= dinv[s]; }
-          sync();
-        }
-        if (r < nrow) {
-          if (r < D.dmax) {
-#pragma unroll
-            for (int s = 0; s < NVS; ++s)
-              if (e[s] >= 0) atomicAdd(s_x + (e[s] >> 20), -(s_qLD[e[s] & 4095] * s_x[(e[s] >> 12) & 255]));
-          } else {
-#pragma unroll
-            for (int s = 0; s < NVS; ++s)
-              if (e[s] >= 0) atomicAdd(s_x + ((e[s] >> 12) & 255), -(s_qLD[e[s] & 4095] * s_x[e[s] >> 20]));
-          }
-          sync();
+      for (int s = 0; s < NVS; ++s) {
+        if (s == 0 || __any(e[s] >= 0)) {
+          if (e[s] >= 0) RR_SOLVE_ADD(s_x + (e[s] >> 20), -(s_qLD[e[s] & 4095] * s_x[(e[s] >> 12) & 255]));
         }
       }
+      sync();
+    }
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; if (d < D.nv) s_x[d] *= dinv[s]; }
+    sync();
+    for (int r = D.dmax; r < 2 * D.dmax; ++r) {  // forward pass (L^-1): x_i -= L_ij x_j
+      int e[NVS];
+#pragma unroll
+      for (int s = 0; s < NVS; ++s) { e[s] = en[s]; en[s] = g_int(tab, (r + 1) * W2 + s * RR_LANES + lane); }
+#pragma unroll
+      for (int s = 0; s < NVS; ++s) {
+        if (s == 0 || __any(e[s] >= 0)) {
+          if (e[s] >= 0) RR_SOLVE_ADD(s_x + ((e[s] >> 12) & 255), -(s_qLD[e[s] & 4095] * s_x[e[s] >> 20]));
+        }
+      }
+      sync();
     }
 #pragma unroll
     for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; x[s] = d < D.nv ? s_x[d] : 0.0f; }
@@ -689,16 +801,16 @@ struct Wave {
       qfrc_smooth[s] = qfrc_actuator[s] = act_dot[s] = 0.0f;
       bias_out[s] = passive_out[s] = 0.0f;
       if (d < D.nv) {
-        const int* di = T.dof_i + RR_DOFI * d;
-        const float* df = T.dof_f + 16 * d;
+        auto di = T.dof_i + RR_DOFI * d;
+        auto df = T.dof_f + 16 * d;
         const float qv = s_qvel[d];
         float passive = -df[1] * qv;
         if (di[2] == 6) passive -= df[2] * (s_qpos[di[6]] - df[3]);
-        const float bias = dot6(s_cdof + 6 * d, s_cfrc + 6 * dofbody[s]);
+        const float bias = dot6(s_cdof + 6 * d, s_cfrc + 6 * ((opaque(dofc0[s]) >> 16) & 255));
         float actf = 0.0f;
         const int u = di[7];
         if (u >= 0) {
-          const float* af = T.act_f + 8 * u;
+          auto af = T.act_f + 8 * u;
           const float c = fminf(fmaxf(s_ctrl[u], af[5]), af[6]);
           const float a = s_act[u];
           act_dot[s] = (c - a) / fmaxf(af[4], RR_MINVAL);
@@ -726,8 +838,8 @@ struct Wave {
 #pragma unroll
       for (int k = 0; k < 9; ++k) con_fr[cs][k] = 0;
       if (c < D.ncon) {
-        const int* ci = T.con_i + 8 * c;
-        const float* cf = T.con_f + 26 * c;
+        auto ci = T.con_i + 8 * c;
+        auto cf = T.con_f + 26 * c;
         const int kind = ci[0], b = ci[1], r = ci[2];
         float gq[4], bq[4], q[4], gm[9], xm[9];
 #pragma unroll
@@ -776,7 +888,7 @@ struct Wave {
         if (dist < 0) {
           con_act[cs] = true;
           float k, bcoef, imp;
-          kbi(D.dt, cf[18], cf[19], cf + 20, dist, k, bcoef, imp);
+          { const float si_[5] = {cf[20], cf[21], cf[22], cf[23], cf[24]}; kbi(D.dt, cf[18], cf[19], si_, dist, k, bcoef, imp); }
           const float rr = fmaxf(cf[17] * (1.0f - imp) / imp, RR_MINVAL);
           con_mu[cs] = cf[16]; con_D[cs] = 1.0f / rr; con_nanc[cs] = ci[4];
           con_kk[cs] = k * imp * dist; con_b[cs] = bcoef;
@@ -798,15 +910,15 @@ struct Wave {
       const int d = lane + RR_LANES * s;
       lim_act[s] = false; lim_sign[s] = 0; lim_D[s] = 0; lim_aref[s] = 0; lim_jar[s] = 0; lim_jv[s] = 0;
       if (d < D.nv) {
-        const int* di = T.dof_i + RR_DOFI * d;
+        auto di = T.dof_i + RR_DOFI * d;
         if (di[8]) {
-          const float* df = T.dof_f + 16 * d;
+          auto df = T.dof_f + 16 * d;
           const float q = s_qpos[di[6]];
           const float dmin_ = q - df[4], dmax_ = df[5] - q;
           const float pos = fminf(dmin_, dmax_);
           if (pos < 0) {
             float k, b, imp;
-            kbi(D.dt, df[6], df[7], df + 8, pos, k, b, imp);
+            { const float si_[5] = {df[8], df[9], df[10], df[11], df[12]}; kbi(D.dt, df[6], df[7], si_, pos, k, b, imp); }
             const float r = fmaxf(df[13] * (1.0f - imp) / imp, RR_MINVAL);
             lim_act[s] = true;
             lim_sign[s] = dmin_ < dmax_ ? 1.0f : -1.0f;
@@ -1053,18 +1165,21 @@ struct Wave {
   template <bool PROF>
   __device__ __forceinline__ int solve() {
     const float scale = 1.0f / (D.meaninertia * (float)(D.nv > 1 ? D.nv : 1));
+    // warm start [UP mjx solver.solve]: cost at qacc_smooth, cost at qacc_warmstart, then the full context at the cheaper
+    // of the two.  One copy of the evaluation code, driven by a wave-uniform phase counter.
+    float cost_smooth = 0.0f;
+    bool use_smooth = false;
+#pragma nounroll
+    for (int ph = 0; ph < 3; ++ph) {
 #pragma unroll
-    for (int s = 0; s < NVS; ++s) qacc[s] = qacc_smooth[s];
-    ctx_create(false);
-    const float cost_smooth = cost;
-#pragma unroll
-    for (int s = 0; s < NVS; ++s) qacc[s] = warm[s];
-    ctx_create(false);
-    if (uni(!(cost < cost_smooth))) {
-#pragma unroll
-      for (int s = 0; s < NVS; ++s) qacc[s] = qacc_smooth[s];
+      for (int s = 0; s < NVS; ++s) qacc[s] = (ph == 0 || (ph == 2 && use_smooth)) ? qacc_smooth[s] : warm[s];
+      ctx_create(false);
+      if (ph == 0) cost_smooth = cost;
+      if (ph == 1) use_smooth = uni(!(cost < cost_smooth));
     }
-    ctx_create(true);
+    update_gradient();
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) search[s] = -Mgrad[s];
     stamp<PROF>(8);
     int niter = 0;
     while (true) {
@@ -1165,14 +1280,14 @@ __global__ __launch_bounds__(RR_LANES, 2) void rr_step_kernel(const RRDims D, co
   for (int s = 0; s < NVS; ++s) {
     const int d = lane + RR_LANES * s;
     w.warm[s] = d < D.nv ? io.warm[(size_t)env * D.nv + d] : 0.0f;
-    w.dofdepth[s] = d < D.nv ? T.dof_i[RR_DOFI * d + 3] : -1;
-    w.dofmadr[s] = d < D.nv ? T.dof_i[RR_DOFI * d + 4] : 0;
-    w.doflast[s] = d < D.nv ? T.dof_i[RR_DOFI * d + 10] : -1;
-    w.dofbody[s] = d < D.nv ? T.dof_i[RR_DOFI * d] : 0;
-    w.dofkind[s] = d < D.nv ? T.dof_i[RR_DOFI * d + 2] : 6;
-    w.dofroot[s] = d < D.nv ? T.dof_i[RR_DOFI * d + 9] : 0;
-    w.dofqadr[s] = d < D.nv ? T.dof_i[RR_DOFI * d + 6] : 0;
-    w.dofq0[s] = (d < D.nv && w.dofkind[s] == 6) ? T.jnt_f[8 * T.dof_i[RR_DOFI * d + 1] + 6] : 0.0f;
+    if (d < D.nv) {
+      auto di = T.dof_i + RR_DOFI * d;
+      w.dofc0[s] = (di[3] & 255) | ((di[2] & 15) << 8) | ((di[9] & 15) << 12) | ((di[0] & 255) << 16) | ((T.body_i[RR_BODYI * di[0]] & 255) << 24);
+      w.dofc1[s] = (di[4] & 0xFFFF) | (di[10] << 16);
+    } else {
+      w.dofc0[s] = 255 | (6 << 8);
+      w.dofc1[s] = 0;
+    }
     w.qacc[s] = w.Ma[s] = w.grad[s] = w.Mgrad[s] = w.search[s] = w.mv[s] = w.qfrc_con[s] = 0.0f;
   }
   // ---- model constants -> registers (once per launch)
@@ -1181,18 +1296,15 @@ __global__ __launch_bounds__(RR_LANES, 2) void rr_step_kernel(const RRDims D, co
   for (int s = 0; s < NBS; ++s) {
     const int b = lane + RR_LANES * s;
     const bool ok = b >= 1 && b < D.nbody;
-    w.bdepth[s] = ok ? T.body_i[RR_BODYI * b + 8] : -1;
-    w.bsib[s] = ok ? T.body_i[RR_BODYI * b + 9] : 0;
+    w.banc[s][0] = ok ? T.body_anc[2 * b] : 0;
+    w.banc[s][1] = ok ? T.body_anc[2 * b + 1] : 0;
+    w.blast[s] = ok ? T.body_i[RR_BODYI * b + 10] : 0;
   }
 #pragma unroll
   for (int it = 0; it < Wave<NBS, NVS, NCS>::NME; ++it) {
     const int e = lane + RR_LANES * it;
-    int v = -1;
-    if (e < D.nM) { const int ij = T.M_ij[e]; v = (ij & 0xffff) | ((ij >> 16) << 8); }
-    w.ment[it] = v;
+    w.ment[it] = e < D.nM ? T.M_ij_k[e] : -1;
   }
-  w.bwd_step_r[0] = lane < D.nbwd ? T.bwd_steps[lane] : 0;
-  w.bwd_step_r[1] = lane + RR_LANES < D.nbwd ? T.bwd_steps[lane + RR_LANES] : 0;
 #pragma unroll
   for (int cs = 0; cs < NCS; ++cs)
 #pragma unroll
@@ -1246,11 +1358,6 @@ __global__ __launch_bounds__(RR_LANES, 2) void rr_step_kernel(const RRDims D, co
       }
     }
     w.contact_geometry(dg);
-    if (lane == 0) {  // world body acceleration = -gravity (cacc shares its cells with qLD)
-      w.s_cacc[0] = w.s_cacc[1] = w.s_cacc[2] = 0.0f;
-      w.s_cacc[3] = -D.gx; w.s_cacc[4] = -D.gy; w.s_cacc[5] = -D.gz;
-    }
-    w.sync();
     w.velocity_sweep();
     w.template stamp<PROF>(2);
     if (last) {   // cinert / cvel of the last forward pass go out now: cinert's cells become the composite inertia next

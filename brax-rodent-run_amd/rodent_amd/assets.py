@@ -10,7 +10,7 @@ import os
 
 from . import mjcf
 
-ASSET_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets")
+ASSET_DIR = os.environ.get("RR_ASSETS") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets")
 MODELS = ("rodent_optimized", "rodent_new", "rodent_pair", "rodent_0")
 
 

@@ -13,7 +13,7 @@ from typing import Dict, Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "librodent_hip.so")
+LIB_PATH = os.environ.get("RR_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "librodent_hip.so")
 
 
 class RRDims(C.Structure):

@@ -67,9 +67,27 @@ def build_kernel_tables(m):
             sib[c] = r
     if int(m["body_jntnum"].max()) > 3:
         raise ValueError("more than 3 joints on one body is not supported by the kernel")
+    blast = np.arange(nb, dtype=np.int32)                 # last body of each subtree (bodies are in DFS order)
+    for b in range(nb - 1, 0, -1):
+        blast[par[b]] = max(blast[par[b]], blast[b])
+    for b in range(1, nb):
+        assert par[b] < b and all(par[c] >= b or c > blast[b] for c in range(b + 1, nb) if c > blast[b] or True)
     k["k_body_i"] = np.stack([par, m["body_jntadr"], m["body_jntnum"], m["body_dofadr"], m["body_dofnum"],
                               k["k_body_root"], child_adr[:-1], child_adr[1:] - child_adr[:-1], depth, sib,
-                              np.zeros(nb, np.int32), np.zeros(nb, np.int32)], axis=1).astype(np.int32)   # 12 ints
+                              blast, np.zeros(nb, np.int32)], axis=1).astype(np.int32)   # 12 ints
+    # pointer-doubling ancestor table: byte k of (anc[2b], anc[2b+1]) = 2^k-th ancestor of body b (0 = none / world)
+    nround = max(1, int(np.ceil(np.log2(max(2, nlevel)))))
+    if nb > 255 or nround > 8:
+        raise ValueError("body count / tree depth above the packed ancestor table")
+    anck = np.zeros((nround, nb), np.int64)
+    anck[0] = par
+    for r in range(1, nround):
+        anck[r] = anck[r - 1][anck[r - 1]]
+    packed_anc = np.zeros((nb, 2), np.int64)
+    for r in range(nround):
+        packed_anc[:, r // 4] |= anck[r] << (8 * (r % 4))
+    k["k_body_anc"] = packed_anc.astype(np.uint32).view(np.int32)
+    k["k_nround"] = np.int32(nround)
     # backward-sweep schedule: (level, sibling rank) steps, deepest level first; level 1 bodies hang off the world
     steps = []
     for L in range(nlevel, 1, -1):
@@ -137,7 +155,12 @@ def build_kernel_tables(m):
         for p, j in enumerate(chain):
             M_ij[Madr[i] + p] = i | (int(j) << 16)
             M_rowadr[Madr[i] + p] = Madr[j]
+    # kernel layout: row | col << 8 per entry, padded with -1 to whole 64-lane rows plus one row of slack (prefetch)
+    nrow = (nM + LANES - 1) // LANES + 1
+    mk = np.full(nrow * LANES, -1, np.int32)
+    mk[:nM] = (M_ij & 0xFFFF) | ((M_ij >> 16) << 8)
     k["k_M_ij"] = M_ij
+    k["k_M_ij_k"] = mk
     k["k_M_rowadr"] = M_rowadr
     # triangular pair table for the factorisation: t -> (p, q), 1 <= p <= q, ordered by q then p
     dmax = int(ddepth.max())
@@ -283,5 +306,14 @@ def build_kernel_tables(m):
         for p in range(int(nanc[c])):
             packed[p // 4, c] |= int(chain_tab[p, c]) << (8 * (p % 4))
     k["k_con_chain_packed"] = packed.astype(np.uint32).view(np.int32)
+    # byte table of all chains back to back (contact c starts at byte coff[c], k_con_i[:,5]); padded, stored as int32 words
+    coff, blob = [], []
+    for c in range(ncon):
+        coff.append(len(blob))
+        d = int(lastdof[c])
+        blob += [int(x) for x in (anc[anc_adr[d]:anc_adr[d + 1]][::-1] if d >= 0 else [])]
+    blob += [0] * (8 - len(blob) % 4)
+    k["k_con_chain_bytes"] = np.frombuffer(bytes(blob), dtype=np.int32).copy()
+
     k["k_jtf"] = lane_table(rows)
     return k
