@@ -311,7 +311,9 @@ struct Wave {
   // round, instead of one serial step per tree level (38-39 of them, a handful of active lanes each).
   // Joint anchors / axes are kept in the parent frame (raw, in the cdof cells) and mapped to the world in com_pos.
   __device__ __forceinline__ BodyC bodyc(int s) const { return s == 0 ? bc0 : load_bodyc(T, lane + RR_LANES * s, D.nbody); }
-  __device__ __forceinline__ int anc_at(int s, int k) const { return (opaque(banc[s][k >> 2]) >> (8 * (k & 3))) & 255; }
+  // k is a run-time round counter: select the word instead of indexing the register array (a dynamic index would
+  // push the whole object into scratch memory)
+  __device__ __forceinline__ int anc_at(int s, int k) const { const int wd = k < 4 ? banc[s][0] : banc[s][1]; return (wd >> (8 * (k & 3))) & 255; }
 
   __device__ __forceinline__ void kinematics() {
 #pragma unroll

@@ -30,11 +30,11 @@ STAGES = [("xpos", "xpos", 2e-6), ("xquat", "xquat", 2e-6), ("xmat", "xmat", 2e-
           ("con_pos", "con_pos", 1e-5), ("con_frame", "con_frame", 1e-5)]
 
 
-@pytest.mark.parametrize("model_name", ["rodent_optimized", "rodent_new"])
+@pytest.mark.parametrize("model_name", ["rodent_optimized", "rodent_new", "rodent_pair"])
 def test_forward_stages_match_oracle(model_name, oracle_built):
     from rodent_amd import assets, hip
     ref = oracle_built
-    N = 48
+    N = 48 if model_name != "rodent_pair" else 16
     st, M, m = util.settled_states(ref, model_name, N, seed=1, iterations=(8, 8))
     dev = torch.device("cuda:0")
     model = hip.Model(assets.asset_path(model_name), iterations=8, ls_iterations=8)

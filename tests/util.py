@@ -25,8 +25,11 @@ def settled_states(ref, model_name, n, seed=0, settle_steps=30, noise=0.02, vel=
     for e in range(n):
         q, v, a, w = base[rng.integers(len(base) // 2, len(base))]
         q = q.copy()
-        q[7:] += rng.uniform(-noise, noise, q.size - 7)
-        q[2] += rng.uniform(-0.004, 0.01)
+        hinge = np.ones(q.size, bool)
+        for r0 in range(0, q.size, 74):           # every replica starts with its 7 free-joint coordinates
+            hinge[r0:r0 + 7] = False
+            q[r0 + 2] += rng.uniform(-0.004, 0.01)
+        q[hinge] += rng.uniform(-noise, noise, int(hinge.sum()))
         out["qpos"].append(q)
         out["qvel"].append(v + rng.uniform(-vel, vel, v.size))
         out["act"].append(np.clip(a + rng.uniform(-0.2, 0.2, a.size), -1, 1))
