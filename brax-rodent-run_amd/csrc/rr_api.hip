@@ -52,7 +52,7 @@ static void layout(rr_model* m) {
   k.o_qLD = take(std::max(std::max(d.nM, 12 * d.nbody), 2 * d.nv));   // also cacc | cfrc and the sin/cos scratch
   const int32_t* jadr = (const int32_t*)m->find("con_jadr")->data;
   k.nJ = jadr[d.ncon];
-  k.o_vec = take(d.nv); k.o_x = take(d.nv); k.o_y = take(d.nv); k.o_arm = take(2 * d.nv);
+  k.o_vec = take(d.nv); k.o_x = take(d.nv); k.o_y = take(d.nv); k.o_arm = take(2 * d.nv); k.o_warm = take(d.nv); k.o_qact = take(d.nv);
   k.lds_floats = o;
   // debug dump
   int g = 0;

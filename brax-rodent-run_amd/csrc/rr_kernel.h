@@ -40,7 +40,7 @@ struct RRDims {
   float dt, gx, gy, gz, tolerance, ls_tolerance, meaninertia;
   // LDS offsets (floats)
   int o_qpos, o_qvel, o_act, o_ctrl, o_xpos, o_xquat, o_cinert, o_cdof, o_cvel,
-      o_qM, o_qLD, o_vec, o_x, o_y, o_arm, o_chain, lds_floats;
+      o_qM, o_qLD, o_vec, o_x, o_y, o_arm, o_chain, o_warm, o_qact, lds_floats;
   // debug dump offsets (floats)
   int g_xpos, g_xquat, g_xmat, g_com, g_cinert, g_crb, g_cdof, g_cvel, g_cfrc, g_qM, g_qLD, g_dinv, g_bias, g_passive,
       g_actuator, g_smooth, g_qacc_smooth, g_con_dist, g_con_pos, g_con_frame, g_con_D, g_con_aref, g_lim, g_qacc,
@@ -244,7 +244,7 @@ struct Wave {
   // consumed / written out), s_cacc|s_cfrc and the sin/cos scratch live in the region that later holds qLD,
   // s_buf reuses xpos|xquat after the contact geometry has been taken.
   float *s_qpos, *s_qvel, *s_act, *s_ctrl, *s_xpos, *s_xquat, *s_cinert, *s_crb, *s_cdof, *s_cvel, *s_cacc,
-      *s_cfrc, *s_buf, *s_sc, *s_qM, *s_qLD, *s_vec, *s_x, *s_y, *s_arm;
+      *s_cfrc, *s_buf, *s_sc, *s_qM, *s_qLD, *s_vec, *s_x, *s_y, *s_arm, *s_warm, *s_qact;
 
   static constexpr int W = NVS * RR_LANES;
   static constexpr int WC = NCS * RR_LANES;
@@ -259,8 +259,8 @@ struct Wave {
   int con_chain[NCS][9];  // ancestor dof chain of the contact's body, leaf first, 4 dof ids per register
   // per-dof registers (slot s -> dof lane + 64 s)
   float dinv[NVS];
-  float qfrc_smooth[NVS], qfrc_actuator[NVS], qacc_smooth[NVS], act_dot[NVS];
-  float qacc[NVS], Ma[NVS], grad[NVS], Mgrad[NVS], search[NVS], mv[NVS], qfrc_con[NVS], warm[NVS];
+  float qfrc_smooth[NVS], qacc_smooth[NVS];
+  float qacc[NVS], Ma[NVS], grad[NVS], Mgrad[NVS], search[NVS], mv[NVS], qfrc_con[NVS];
   // limit rows (one per limited hinge dof)
   float lim_sign[NVS], lim_D[NVS], lim_aref[NVS], lim_jar[NVS], lim_jv[NVS];
   bool lim_act[NVS];
@@ -283,7 +283,7 @@ struct Wave {
     s_xpos = l + d.o_xpos; s_xquat = l + d.o_xquat; s_cinert = l + d.o_cinert; s_crb = s_cinert;
     s_cdof = l + d.o_cdof; s_cvel = l + d.o_cvel; s_qM = l + d.o_qM; s_qLD = l + d.o_qLD;
     s_cacc = s_qLD; s_cfrc = s_qLD + 6 * d.nbody; s_sc = s_qLD; s_buf = s_xpos;
-    s_vec = l + d.o_vec; s_x = l + d.o_x; s_y = l + d.o_y; s_arm = l + d.o_arm;
+    s_vec = l + d.o_vec; s_x = l + d.o_x; s_y = l + d.o_y; s_arm = l + d.o_arm; s_warm = l + d.o_warm; s_qact = l + d.o_qact;
   }
 
   // One wavefront owns the environment: its LDS instructions execute in program order, so a
@@ -800,7 +800,7 @@ struct Wave {
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
       const int d = lane + RR_LANES * s;
-      qfrc_smooth[s] = qfrc_actuator[s] = act_dot[s] = 0.0f;
+      qfrc_smooth[s] = 0.0f;
       bias_out[s] = passive_out[s] = 0.0f;
       if (d < D.nv) {
         auto di = T.dof_i + RR_DOFI * d;
@@ -813,12 +813,10 @@ struct Wave {
         const int u = di[7];
         if (u >= 0) {
           auto af = T.act_f + 8 * u;
-          const float c = fminf(fmaxf(s_ctrl[u], af[5]), af[6]);
           const float a = s_act[u];
-          act_dot[s] = (c - a) / fmaxf(af[4], RR_MINVAL);
           actf = af[0] * a + af[1] + af[2] * s_qpos[di[6]] + af[3] * qv;
         }
-        qfrc_actuator[s] = actf;
+        s_qact[d] = actf;
         qfrc_smooth[s] = passive - bias + actf;
         bias_out[s] = bias; passive_out[s] = passive;
       }
@@ -1174,7 +1172,7 @@ struct Wave {
 #pragma nounroll
     for (int ph = 0; ph < 3; ++ph) {
 #pragma unroll
-      for (int s = 0; s < NVS; ++s) qacc[s] = (ph == 0 || (ph == 2 && use_smooth)) ? qacc_smooth[s] : warm[s];
+      for (int s = 0; s < NVS; ++s) qacc[s] = (ph == 0 || (ph == 2 && use_smooth)) ? qacc_smooth[s] : (lane + RR_LANES * s < D.nv ? s_warm[lane + RR_LANES * s] : 0.0f);
       ctx_create(false);
       if (ph == 0) cost_smooth = cost;
       if (ph == 1) use_smooth = uni(!(cost < cost_smooth));
@@ -1214,7 +1212,7 @@ struct Wave {
       ++niter;
     }
 #pragma unroll
-    for (int s = 0; s < NVS; ++s) warm[s] = qacc[s];
+    for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; if (d < D.nv) s_warm[d] = qacc[s]; }
     return niter;
   }
 
@@ -1230,7 +1228,11 @@ struct Wave {
       const int d = lane + RR_LANES * s;
       if (d < D.nv) {
         const int u = T.dof_i[RR_DOFI * d + 7];
-        if (u >= 0) s_act[u] += D.dt * act_dot[s];
+        if (u >= 0) {   // filter activation dynamics: act_dot = (clamp(ctrl) - act) / tau
+          auto af = T.act_f + 8 * u;
+          const float c = fminf(fmaxf(s_ctrl[u], af[5]), af[6]);
+          s_act[u] += D.dt * ((c - s_act[u]) / fmaxf(af[4], RR_MINVAL));
+        }
         s_qvel[d] += D.dt * qa[s];
       }
     }
@@ -1281,7 +1283,7 @@ __global__ __launch_bounds__(RR_LANES, 2) void rr_step_kernel(const RRDims D, co
 #pragma unroll
   for (int s = 0; s < NVS; ++s) {
     const int d = lane + RR_LANES * s;
-    w.warm[s] = d < D.nv ? io.warm[(size_t)env * D.nv + d] : 0.0f;
+    if (d < D.nv) w.s_warm[d] = io.warm[(size_t)env * D.nv + d];
     if (d < D.nv) {
       auto di = T.dof_i + RR_DOFI * d;
       w.dofc0[s] = (di[3] & 255) | ((di[2] & 15) << 8) | ((di[9] & 15) << 12) | ((di[0] & 255) << 16) | ((T.body_i[RR_BODYI * di[0]] & 255) << 24);
@@ -1292,25 +1294,6 @@ __global__ __launch_bounds__(RR_LANES, 2) void rr_step_kernel(const RRDims D, co
     }
     w.qacc[s] = w.Ma[s] = w.grad[s] = w.Mgrad[s] = w.search[s] = w.mv[s] = w.qfrc_con[s] = 0.0f;
   }
-  // ---- model constants -> registers (once per launch)
-  w.bc0 = load_bodyc(T, lane, D.nbody);
-#pragma unroll
-  for (int s = 0; s < NBS; ++s) {
-    const int b = lane + RR_LANES * s;
-    const bool ok = b >= 1 && b < D.nbody;
-    w.banc[s][0] = ok ? T.body_anc[2 * b] : 0;
-    w.banc[s][1] = ok ? T.body_anc[2 * b + 1] : 0;
-    w.blast[s] = ok ? T.body_i[RR_BODYI * b + 10] : 0;
-  }
-#pragma unroll
-  for (int it = 0; it < Wave<NBS, NVS, NCS>::NME; ++it) {
-    const int e = lane + RR_LANES * it;
-    w.ment[it] = e < D.nM ? T.M_ij_k[e] : -1;
-  }
-#pragma unroll
-  for (int cs = 0; cs < NCS; ++cs)
-#pragma unroll
-    for (int k = 0; k < 9; ++k) w.con_chain[cs][k] = T.con_chain_packed[k * (NCS * RR_LANES) + cs * RR_LANES + lane];
   for (int i = lane; i < D.nv; i += RR_LANES) w.s_arm[i] = T.dof_f[16 * i];
   if (lane == 0) {  // world body entries that no phase overwrites
     for (int k = 0; k < 6; ++k) w.s_cvel[k] = 0.0f;
@@ -1327,6 +1310,21 @@ __global__ __launch_bounds__(RR_LANES, 2) void rr_step_kernel(const RRDims D, co
     float* dg = last ? dbg : nullptr;
     float bias[NVS], passive[NVS];
     w.template stamp<PROF>(15);
+    // ---- per-substep (re)load of the model constants from the L2-resident tables.  Holding them in registers across
+    // the solver made the allocator spill them to scratch (HBM-side write traffic ~80x the algorithmic bytes); a plain
+    // reload costs the same read and no write.  `opaque` keeps the loads inside the substep loop.
+    {
+      const int ol = opaque(lane);
+      w.bc0 = load_bodyc(T, ol, D.nbody);
+#pragma unroll
+      for (int s = 0; s < NBS; ++s) {
+        const int b = ol + RR_LANES * s;
+        const bool ok = b >= 1 && b < D.nbody;
+        w.banc[s][0] = ok ? T.body_anc[2 * b] : 0;
+        w.banc[s][1] = ok ? T.body_anc[2 * b + 1] : 0;
+        w.blast[s] = ok ? T.body_i[RR_BODYI * b + 10] : 0;
+      }
+    }
     if (lane == 0) {  // world body pose (its LDS cells are reused by later phases of every substep)
       for (int k = 0; k < 3; ++k) w.s_xpos[k] = 0.0f;
       w.s_xquat[0] = 1.0f; w.s_xquat[1] = w.s_xquat[2] = w.s_xquat[3] = 0.0f;
@@ -1380,6 +1378,18 @@ __global__ __launch_bounds__(RR_LANES, 2) void rr_step_kernel(const RRDims D, co
       for (int e = lane; e < 10 * D.nbody; e += RR_LANES) dg[D.g_crb + e] = w.s_crb[e];
       for (int e = lane; e < 6 * D.nbody; e += RR_LANES) dg[D.g_cfrc + e] = w.s_cfrc[e];
     }
+    {   // sparse-matrix entry ids and contact chains: needed from here to the end of the substep
+      const int ol = opaque(lane);
+#pragma unroll
+      for (int it = 0; it < Wave<NBS, NVS, NCS>::NME; ++it) {
+        const int e = ol + RR_LANES * it;
+        w.ment[it] = e < D.nM ? T.M_ij_k[e] : -1;
+      }
+#pragma unroll
+      for (int cs = 0; cs < NCS; ++cs)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) w.con_chain[cs][k] = T.con_chain_packed[k * (NCS * RR_LANES) + cs * RR_LANES + ol];
+    }
     w.sync();
     w.mass_matrix();
     w.template stamp<PROF>(4);
@@ -1396,7 +1406,7 @@ __global__ __launch_bounds__(RR_LANES, 2) void rr_step_kernel(const RRDims D, co
         const int d = lane + RR_LANES * s;
         if (d < D.nv) {
           dg[D.g_dinv + d] = w.dinv[s]; dg[D.g_bias + d] = bias[s]; dg[D.g_passive + d] = passive[s];
-          dg[D.g_actuator + d] = w.qfrc_actuator[s]; dg[D.g_smooth + d] = w.qfrc_smooth[s];
+          dg[D.g_actuator + d] = w.s_qact[d]; dg[D.g_smooth + d] = w.qfrc_smooth[s];
           dg[D.g_qacc_smooth + d] = w.qacc_smooth[s];
         }
       }
@@ -1427,8 +1437,8 @@ __global__ __launch_bounds__(RR_LANES, 2) void rr_step_kernel(const RRDims D, co
   for (int s = 0; s < NVS; ++s) {
     const int d = lane + RR_LANES * s;
     if (d < D.nv) {
-      io.warm[(size_t)env * D.nv + d] = w.warm[s];
-      if (io.o_qfrc_actuator) io.o_qfrc_actuator[(size_t)env * D.nv + d] = w.qfrc_actuator[s];
+      io.warm[(size_t)env * D.nv + d] = w.s_warm[d];
+      if (io.o_qfrc_actuator) io.o_qfrc_actuator[(size_t)env * D.nv + d] = w.s_qact[d];
     }
   }
 
@@ -1447,7 +1457,7 @@ __global__ __launch_bounds__(RR_LANES, 2) void rr_step_kernel(const RRDims D, co
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
       const int d = lane + RR_LANES * s;
-      if (d < D.nv) ob[o + d] = w.qfrc_actuator[s];
+      if (d < D.nv) ob[o + d] = w.s_qact[d];
     }
     o += D.nv;
     if (lane < 3) {  // xmat[1] @ (track_pos[frame + 1] - qpos[:3]); JAX clamps the gather index
