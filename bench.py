@@ -47,6 +47,19 @@ def host_cores():
     return min(n, int(os.environ.get("RR_CPU_THREADS", "16")))
 
 
+def pmc_traffic():
+    """HBM-side bytes per launch of the step kernel from the latest committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE are collected in their own runs, tools/pmc_traffic.py); None when no summary is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        return float(json.load(open(files[-1]))["traffic_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(n_envs=512, steps=100):
     """The oracle (kind 'port': our C restatement; the reference JAX path cannot run here) timed on the host cores."""
     from oracle import ref
@@ -152,7 +165,7 @@ def main():
                                    f"CG 8/8, n_frames 10", "envs_per_gpu": N, "global_envs": N * world,
                        "parallelism": f"env-shards x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
                          "kernel": "rr_step_kernel", "avg_kernel_ms": avg_kernel_s * 1e3, "launches": launches,
                          "algorithmic_bytes_per_env_step": bytes_per_env_step},
             "cpu_baseline": None,
