@@ -106,7 +106,9 @@ def train(
         for p in params:
             torch.distributed.broadcast(p.data, src=0)
     flat = D.FlatGrads(params)
-    optimizer = torch.optim.Adam(params, lr=learning_rate, betas=(0.9, 0.999), eps=1e-8)
+    # optax.adam(lr): b1=.9, b2=.999, eps=1e-8, eps outside the sqrt -- torch.optim.Adam's update; one fused
+    # multi-tensor launch per step on the GPU
+    optimizer = torch.optim.Adam(params, lr=learning_rate, betas=(0.9, 0.999), eps=1e-8, fused=(device.type == "cuda"))
     normalizer_params = running_statistics.init_state(env.observation_size, device)
     normalize = running_statistics.normalize if normalize_observations else (lambda x, y: x)
     make_policy = ppo_networks_mod.make_inference_fn(ppo_network)
