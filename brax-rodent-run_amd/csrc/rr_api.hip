@@ -295,6 +295,40 @@ extern "C" int rr_env_reset(rr_batch* b, const rr_state* st, const rr_env_io* en
   return launch(b, st, nullptr, 1, env, out, 2);
 }
 
+// ------------------------------------------------------------------------------------------ PPO: GAE
+__global__ void rr_gae_kernel(const float* __restrict__ trunc, const float* __restrict__ term, const float* __restrict__ rew,
+                              const float* __restrict__ val, const float* __restrict__ boot, int T, int B, float lam, float disc,
+                              float* __restrict__ vs, float* __restrict__ adv) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float acc = 0.0f;
+  const float vb = boot[b];
+  for (int t = T - 1; t >= 0; --t) {     // vs_t - v_t = delta_t + gamma (1-term_t)(1-trunc_t) lambda (vs_{t+1} - v_{t+1})
+    const size_t i = (size_t)t * B + b;
+    const float mask = 1.0f - trunc[i], nt = 1.0f - term[i];
+    const float vnext = t == T - 1 ? vb : val[i + B];
+    const float delta = (rew[i] + disc * nt * vnext - val[i]) * mask;
+    acc = delta + disc * nt * mask * lam * acc;
+    vs[i] = acc + val[i];
+  }
+  for (int t = 0; t < T; ++t) {          // advantages use vs_{t+1} (bootstrap at the end)
+    const size_t i = (size_t)t * B + b;
+    const float vsn = t == T - 1 ? vb : vs[i + B];
+    adv[i] = (rew[i] + disc * (1.0f - term[i]) * vsn - val[i]) * (1.0f - trunc[i]);
+  }
+}
+
+extern "C" int rr_compute_gae(const float* truncation, const float* termination, const float* rewards, const float* values,
+                              const float* bootstrap_value, int32_t T, int32_t B, float lambda_, float discount, float* vs,
+                              float* advantages, void* stream) {
+  if (!truncation || !termination || !rewards || !values || !bootstrap_value || !vs || !advantages || T <= 0 || B <= 0)
+    return fail(RR_EINVAL, "rr_compute_gae: bad argument");
+  hipLaunchKernelGGL(rr_gae_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, truncation, termination, rewards,
+                     values, bootstrap_value, T, B, lambda_, discount, vs, advantages);
+  HIPCHK(hipGetLastError());
+  return RR_OK;
+}
+
 extern "C" int rr_debug_layout(const rr_batch* b, const char*** names, const int32_t** offsets, const int32_t** sizes) {
   if (!b) return fail(RR_EINVAL, "rr_debug_layout: null batch");
   if (names) *names = const_cast<const char**>(b->m->dbg_cnames.data());

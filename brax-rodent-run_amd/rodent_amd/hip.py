@@ -39,7 +39,7 @@ class RREnvIO(C.Structure):
 
 EXPORTS = ["rr_model_load", "rr_model_dims", "rr_model_set_solver", "rr_model_destroy", "rr_batch_create",
            "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset",
-           "rr_debug_layout", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
+           "rr_compute_gae", "rr_debug_layout", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
 
 _lib = None
 
@@ -67,6 +67,7 @@ def lib():
         L.rr_env_reset.argtypes = [C.c_void_p, C.POINTER(RRState), C.POINTER(RREnvIO), C.POINTER(RROutputs)]
         L.rr_debug_layout.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_int32)),
                                       C.POINTER(C.POINTER(C.c_int32))]
+        L.rr_compute_gae.argtypes = [C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rr_batch_set_profile.argtypes = [C.c_void_p, C.c_void_p]
         L.rr_batch_set_timing.argtypes = [C.c_void_p, C.c_int32]
         L.rr_batch_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -210,3 +211,17 @@ class Batch:
         ms, n = C.c_double(), C.c_int64()
         _check(lib().rr_batch_kernel_time(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+def compute_gae(truncation, termination, rewards, values, bootstrap_value, lambda_: float, discount: float):
+    """GAE on the GPU in one launch (C ABI `rr_compute_gae`): inputs time-major [T, B] float32 device tensors."""
+    T, B = values.shape
+    args = [t.contiguous() for t in (truncation, termination, rewards, values, bootstrap_value)]
+    for t in args:
+        _ptr(t)
+    vs = torch.empty_like(args[3])
+    adv = torch.empty_like(args[3])
+    stream = torch.cuda.current_stream(values.device).cuda_stream
+    _check(lib().rr_compute_gae(*[t.data_ptr() for t in args], T, B, float(lambda_), float(discount), vs.data_ptr(),
+                                adv.data_ptr(), C.c_void_p(stream)))
+    return vs, adv

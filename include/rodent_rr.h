@@ -106,6 +106,13 @@ int rr_env_step(rr_batch* b, const rr_state* st, const float* action, int32_t n_
  * implemented as rr_pipeline_init + obs epilogue in one launch. Only env->obs/track_pos/cur_frame are used. */
 int rr_env_reset(rr_batch* b, const rr_state* st, const rr_env_io* env, const rr_outputs* out);
 
+/* Generalised advantage estimation of one PPO minibatch, the reverse scan of brax.training.agents.ppo.losses.compute_gae
+ * [UP; SURVEY.md Appendix E], one thread per trajectory.  All arrays time-major [T][B] device float32; bootstrap [B];
+ * outputs vs [T][B] and advantages [T][B].  `stream` is a hipStream_t (NULL = default stream). */
+int rr_compute_gae(const float* truncation, const float* termination, const float* rewards, const float* values,
+                   const float* bootstrap_value, int32_t T, int32_t B, float lambda_, float discount, float* vs,
+                   float* advantages, void* stream);
+
 /* Debug dump layout: names[i] begins at float offsets[i] of each env's debug row; returns the field count. */
 int rr_debug_layout(const rr_batch* b, const char*** names, const int32_t** offsets, const int32_t** sizes);
 

@@ -29,3 +29,17 @@ def test_ppo_train_on_rodent_env():
     act, _ = pol(torch.zeros(2, env.observation_size, device="cuda:0"))
     assert act.shape == (2, env.action_size) and torch.isfinite(act).all()
     assert timing and timing[0]["rollout_s"] > 0
+
+
+def test_gae_kernel_matches_torch_scan():
+    from rodent_amd.training.agents.ppo import losses
+    g = torch.Generator().manual_seed(0)
+    T, B = 10, 3001
+    r, v = torch.randn(T, B, generator=g), torch.randn(T, B, generator=g)
+    boot = torch.randn(B, generator=g)
+    trunc = (torch.rand(T, B, generator=g) < 0.1).float()
+    term = (torch.rand(T, B, generator=g) < 0.2).float() * (1 - trunc)
+    want_vs, want_adv = losses.compute_gae(trunc, term, r, v, boot, lambda_=0.95, discount=0.97)          # CPU: torch scan
+    got_vs, got_adv = losses.compute_gae(*(x.cuda() for x in (trunc, term, r, v, boot)), lambda_=0.95, discount=0.97)
+    torch.testing.assert_close(got_vs.cpu(), want_vs, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(got_adv.cpu(), want_adv, rtol=1e-5, atol=1e-5)
