@@ -100,13 +100,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal on a 1-GPU box: RR_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo (RCCL refuses two ranks
+    # on one device); the driver's multi-GPU run uses one GPU per rank over RCCL
+    share = os.environ.get("RR_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
     else:
         dist = None
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
     from rodent_amd import envs
@@ -144,7 +151,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms, launches = env._batch.kernel_time()
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if share else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(state.obs).all(), "non-finite observation in the rollout"
