@@ -1264,7 +1264,7 @@ struct Wave {
 
 // ------------------------------------------------------------------------------------------ kernel
 template <int NBS, int NVS, int NCS, bool PROF>
-__global__ __launch_bounds__(RR_LANES, 2) void rr_step_kernel(const RRDims D, const RRTables T, const RRIO io, const int num_envs,
+__global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(const RRDims D, const RRTables T, const RRIO io, const int num_envs,
                                                            const int n_frames) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int env = blockIdx.x;
