@@ -36,7 +36,7 @@
 
 struct RRDims {
   int nq, nv, nu, nbody, njnt, nM, ncon, nlevel, dmax, nroot;
-  int T_mulm, T_jtf, T_chain, obs_dim, iterations, ls_iterations, nJ, ntri, nbwd, nfac, nround, nchain, nment;
+  int T_mulm, T_jtf, T_chain, obs_dim, iterations, ls_iterations, nJ, ntri, nbwd, nfac, nround, nchain, nment, nsolb;
   float dt, gx, gy, gz, tolerance, ls_tolerance, meaninertia;
   // LDS offsets (floats)
   int o_qpos, o_qvel, o_act, o_ctrl, o_xpos, o_xquat, o_cinert, o_cdof, o_cvel,
@@ -51,7 +51,7 @@ struct RRDims {
 typedef const int __attribute__((address_space(1)))* rr_gi;
 typedef const float __attribute__((address_space(1)))* rr_gf;
 struct RRTables {
-  rr_gi lvl_adr, lvl_body, child, body_i, jnt_i, dof_i, M_ij_k, M_rowadr, tri, mulm, solve_fwd, solve_bwd,
+  rr_gi solveb, solveb_last, solvef, solvef_meta, lvl_adr, lvl_body, child, body_i, jnt_i, dof_i, M_ij_k, M_rowadr, tri, mulm, solve_fwd, solve_bwd,
       solve_bwd_adr, solve_bwd_level, bwd_steps, body_anc, con_chain_packed, solve2, solve_seq, factor2, factor2_first, con_i, con_chain, jtf;
   rr_gf body_f, jnt_f, dof_f, act_f, con_f, root_mass;
 };
@@ -234,6 +234,34 @@ __device__ __forceinline__ BodyC load_bodyc(const RRTables& T, int b, int nbody)
 }
 
 // ------------------------------------------------------------------------------------------ the wave
+// ---- diagnostic builds only (tools/rep_bench.py): run a phase REP extra times to read its marginal in-situ cost
+#ifndef RR_REP_SOLVE
+#define RR_REP_SOLVE 0
+#endif
+#ifndef RR_REP_FACTOR
+#define RR_REP_FACTOR 0
+#endif
+#ifndef RR_REP_LS
+#define RR_REP_LS 0
+#endif
+#ifndef RR_REP_UC
+#define RR_REP_UC 0
+#endif
+#ifndef RR_REP_MULM
+#define RR_REP_MULM 0
+#endif
+#ifndef RR_REP_JAC
+#define RR_REP_JAC 0
+#endif
+#ifndef RR_REP_LSEVAL
+#define RR_REP_LSEVAL 0
+#endif
+#ifndef RR_REP_MM
+#define RR_REP_MM 0
+#endif
+#ifndef RR_REP_KIN
+#define RR_REP_KIN 0
+#endif
 template <int NBS, int NVS, int NCS>
 struct Wave {
   const RRDims& D;
@@ -716,51 +744,76 @@ struct Wave {
     sync();
   }
 
-  // x <- (L' D L)^-1 x  [MuJoCo mj_solveLD], level-parallel: row `l` of k_solve2 holds every entry (i, j) of the dofs
-  // i of depth l+1 side by side on the lanes.  Backward pass (L^-T), deep -> shallow: x_j -= L_ij x_i; forward pass
-  // (L^-1), shallow -> deep: x_i -= L_ij x_j; both as LDS float atomics on the vector in s_x.  2*dmax LDS hand-offs
-  // per solve instead of one per (level, descendant) row; the next table row is prefetched.
+  // x <- (L' D L)^-1 x  [MuJoCo mj_solveLD], level-parallel and ATOMIC-FREE (an LDS float atomic costs ~10x a plain LDS
+  // read-modify-write on gfx950 and >1000 cycles with every wave of the CU issuing them).  Lane d owns x_d in a register.
+  //  backward (L^-T), deep -> shallow: gather rows -- lane j adds L_ij x_i over the dofs i of the level below it (one
+  //  table row per contributor rank), then x_j -= acc and republishes x_j;
+  //  forward (L^-1), shallow -> deep: one entry-parallel row of products L_ij x_j per level, summed per dof of the level
+  //  by a DPP wave reduction (dof rank in bits 28..31 of the entry) and applied by the owner lane.
+  //  One LDS hand-off per level in each pass; table rows are prefetched one ahead.
+#ifdef RR_EXP_NOLOAD
+#define SOLB(i) ((((i) * 7 + 3) & 1023) | ((((i) * 5) & 63) << 12))
+#define SOLF(i) ((((i) * 7 + 3) & 1023) | ((((i) * 5) & 63) << 20) | (((i) & 1) << 28))
+#else
+#define SOLB(i) g_int(T.solveb, (i))
+#define SOLF(i) g_int(T.solvef, (i))
+#endif
   __device__ __forceinline__ void ldl_solve(float* x) {
     constexpr int W2 = NVS * RR_LANES;
+    float xr[NVS], acc[NVS];
 #pragma unroll
-    for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; if (d < D.nv) s_x[d] = x[s]; }
-    // k_solve_seq: dmax backward rows (deep -> shallow), then dmax forward rows (shallow -> deep).  Slots beyond the
-    // first hold entries only at the few levels with more than 64 of them: skipped by a wave-uniform test.
-    auto tab = T.solve_seq;
+    for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; xr[s] = x[s]; acc[s] = 0.0f; if (d < D.nv) s_x[d] = x[s]; }
     int en[NVS];
 #pragma unroll
-    for (int s = 0; s < NVS; ++s) en[s] = g_int(tab, s * RR_LANES + lane);
+    for (int s = 0; s < NVS; ++s) en[s] = SOLB(s * RR_LANES + lane);
+    int lastn = g_int(T.solveb_last, 0);
     sync();
-    for (int r = 0; r < D.dmax; ++r) {           // backward pass (L^-T): x_j -= L_ij x_i
+    for (int r = 0; r < D.nsolb; ++r) {
       int e[NVS];
+      const int last = lastn;
 #pragma unroll
-      for (int s = 0; s < NVS; ++s) { e[s] = en[s]; en[s] = g_int(tab, (r + 1) * W2 + s * RR_LANES + lane); }
+      for (int s = 0; s < NVS; ++s) { e[s] = en[s]; en[s] = SOLB((r + 1) * W2 + s * RR_LANES + lane); }
+      lastn = g_int(T.solveb_last, r + 1);
 #pragma unroll
-      for (int s = 0; s < NVS; ++s) {
-        if (s == 0 || __any(e[s] >= 0)) {
-          if (e[s] >= 0) RR_SOLVE_ADD(s_x + (e[s] >> 20), -(s_qLD[e[s] & 4095] * s_x[(e[s] >> 12) & 255]));
+      for (int s = 0; s < NVS; ++s)
+        if (e[s] >= 0) acc[s] += s_qLD[e[s] & 4095] * s_x[e[s] >> 12];
+      if (last) {
+#pragma unroll
+        for (int s = 0; s < NVS; ++s) {
+          const int d = lane + RR_LANES * s;
+          xr[s] -= acc[s]; acc[s] = 0.0f;
+          if (d < D.nv) s_x[d] = xr[s];
         }
+        sync();
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; xr[s] *= dinv[s]; if (d < D.nv) s_x[d] = xr[s]; }
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) en[s] = SOLF(s * RR_LANES + lane);
+    sync();
+    for (int l = 0; l < D.dmax; ++l) {
+      int e[NVS];
+      float prod[NVS];
+#pragma unroll
+      for (int s = 0; s < NVS; ++s) { e[s] = en[s]; en[s] = SOLF((l + 1) * W2 + s * RR_LANES + lane); }
+#pragma unroll
+      for (int s = 0; s < NVS; ++s) prod[s] = e[s] != -1 ? s_qLD[e[s] & 4095] * s_x[(e[s] >> 20) & 255] : 0.0f;
+      const int nl = g_int(T.solvef_meta, 16 * l);
+      for (int r = 0; r < nl; ++r) {
+        float v = 0.0f;
+#pragma unroll
+        for (int s = 0; s < NVS; ++s) v += (e[s] != -1 && (int)((unsigned)e[s] >> 28) == r) ? prod[s] : 0.0f;
+        v = wave_sum(v);
+        const int i = g_int(T.solvef_meta, 16 * l + 1 + r);     // wave-uniform dof id of rank r
+#pragma unroll
+        for (int s = 0; s < NVS; ++s)
+          if (lane + RR_LANES * s == i) { xr[s] -= v; s_x[i] = xr[s]; }
       }
       sync();
     }
 #pragma unroll
-    for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; if (d < D.nv) s_x[d] *= dinv[s]; }
-    sync();
-    for (int r = D.dmax; r < 2 * D.dmax; ++r) {  // forward pass (L^-1): x_i -= L_ij x_j
-      int e[NVS];
-#pragma unroll
-      for (int s = 0; s < NVS; ++s) { e[s] = en[s]; en[s] = g_int(tab, (r + 1) * W2 + s * RR_LANES + lane); }
-#pragma unroll
-      for (int s = 0; s < NVS; ++s) {
-        if (s == 0 || __any(e[s] >= 0)) {
-          if (e[s] >= 0) RR_SOLVE_ADD(s_x + ((e[s] >> 12) & 255), -(s_qLD[e[s] & 4095] * s_x[e[s] >> 20]));
-        }
-      }
-      sync();
-    }
-#pragma unroll
-    for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; x[s] = d < D.nv ? s_x[d] : 0.0f; }
-    sync();  // s_x may be rewritten by the next call
+    for (int s = 0; s < NVS; ++s) x[s] = xr[s];
   }
 
   // y = M * s_vec (s_vec must be visible).  Entry-parallel: lane owns matrix entries e = lane + 64 it (row/col ids
@@ -1042,11 +1095,13 @@ struct Wave {
   __device__ __forceinline__ void update_gradient() {
 #pragma unroll
     for (int s = 0; s < NVS; ++s) { grad[s] = Ma[s] - qfrc_smooth[s] - qfrc_con[s]; Mgrad[s] = grad[s]; }
+    for (int rep = 0; rep < RR_REP_SOLVE; ++rep) { float t_[NVS]; for (int s = 0; s < NVS; ++s) t_[s] = grad[s]; ldl_solve(t_); }
     ldl_solve(Mgrad);
   }
 
   // [UP mjx solver._Context.create]: Jaref, Ma, constraint state (and gradient/search) at `qacc`
-  __device__ __forceinline__ void ctx_create(bool with_grad) {
+  // `at_smooth`: qacc == qacc_smooth, where Ma = M qacc_smooth = qfrc_smooth by construction (no product needed)
+  __device__ __forceinline__ void ctx_create(bool at_smooth) {
     put_vec(qacc);
     jac_mul(con_jar, s_vec);
 #pragma unroll
@@ -1055,14 +1110,14 @@ struct Wave {
       for (int k = 0; k < 4; ++k) con_jar[cs][k] -= con_aref[cs][k];
 #pragma unroll
     for (int s = 0; s < NVS; ++s) lim_jar[s] = lim_sign[s] * qacc[s] - lim_aref[s];
-    mul_m(Ma);
+    if (at_smooth) {
+#pragma unroll
+      for (int s = 0; s < NVS; ++s) Ma[s] = qfrc_smooth[s];
+    } else {
+      mul_m(Ma);
+    }
     cost = INFINITY; prev_cost = 0.0f;
     update_constraint();
-    if (with_grad) {
-      update_gradient();
-#pragma unroll
-      for (int s = 0; s < NVS; ++s) search[s] = -Mgrad[s];
-    }
   }
 
   // line-search point(s): cost and derivatives of the piecewise-quadratic 1-D cost at alpha
@@ -1109,8 +1164,8 @@ struct Wave {
   // [UP mjx solver._linesearch]
   __device__ __forceinline__ void linesearch() {
     float red[4] = {0, 0, 0, 0};
-    put_vec(search);
-    mul_m(mv);
+    put_vec(search);   // mv = M search is carried by the caller's recurrence
+    for (int rep = 0; rep < RR_REP_JAC; ++rep) jac_mul(con_jv, s_vec);
     jac_mul(con_jv, s_vec);
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
@@ -1137,6 +1192,7 @@ struct Wave {
       done |= (hi.d0 > 0) && (hi.d0 < gtol);
       if (uni(done)) break;
       const float a3[3] = {lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, 0.5f * (lo.alpha + hi.alpha)};
+      for (int rep = 0; rep < RR_REP_LSEVAL; ++rep) { ls_eval<3>(a3, qg, tmp3); asm volatile("" :: "v"(tmp3[0].cost), "v"(tmp3[1].cost), "v"(tmp3[2].cost)); }
       ls_eval<3>(a3, qg, tmp3);
       const LSPoint lo_next = tmp3[0], hi_next = tmp3[1], mid = tmp3[2];
       const bool swap_lo_next = (lo.d0 > 0) || (lo.d0 < lo_next.d0);
@@ -1171,15 +1227,18 @@ struct Wave {
     bool use_smooth = false;
 #pragma nounroll
     for (int ph = 0; ph < 3; ++ph) {
+      if (ph == 2 && !use_smooth) break;        // the context already is the one at qacc_warmstart
 #pragma unroll
-      for (int s = 0; s < NVS; ++s) qacc[s] = (ph == 0 || (ph == 2 && use_smooth)) ? qacc_smooth[s] : (lane + RR_LANES * s < D.nv ? s_warm[lane + RR_LANES * s] : 0.0f);
-      ctx_create(false);
+      for (int s = 0; s < NVS; ++s) qacc[s] = ph != 1 ? qacc_smooth[s] : (lane + RR_LANES * s < D.nv ? s_warm[lane + RR_LANES * s] : 0.0f);
+      ctx_create(ph != 1);
       if (ph == 0) cost_smooth = cost;
       if (ph == 1) use_smooth = uni(!(cost < cost_smooth));
     }
     update_gradient();
+    // search = -Mgrad, and mv = M search = -grad because Mgrad = M^-1 grad: the product the reference recomputes every
+    // iteration [UP mjx solver._linesearch: mv = M @ search] follows the search-direction recurrence exactly
 #pragma unroll
-    for (int s = 0; s < NVS; ++s) search[s] = -Mgrad[s];
+    for (int s = 0; s < NVS; ++s) { search[s] = -Mgrad[s]; mv[s] = -grad[s]; }
     stamp<PROF>(8);
     int niter = 0;
     while (true) {
@@ -1193,11 +1252,13 @@ struct Wave {
       done |= gradient < D.tolerance;
       if (uni(done)) break;
       stamp<PROF>(12);
+      for (int rep = 0; rep < RR_REP_LS; ++rep) linesearch();
       linesearch();
       stamp<PROF>(9);
       float pm[NVS], gg = 0.0f;
 #pragma unroll
       for (int s = 0; s < NVS; ++s) { gg += grad[s] * Mgrad[s]; pm[s] = Mgrad[s]; }
+      for (int rep = 0; rep < RR_REP_UC; ++rep) { const float pc = prev_cost, c0 = cost; update_constraint(); prev_cost = pc; cost = c0; }
       update_constraint();
       stamp<PROF>(10);
       update_gradient();
@@ -1208,7 +1269,7 @@ struct Wave {
       wave_sum_n<2>(bt);
       const float beta = fmaxf(0.0f, bt[0] / fmaxf(RR_MINVAL, bt[1]));
 #pragma unroll
-      for (int s = 0; s < NVS; ++s) search[s] = -Mgrad[s] + beta * search[s];
+      for (int s = 0; s < NVS; ++s) { search[s] = -Mgrad[s] + beta * search[s]; mv[s] = -grad[s] + beta * mv[s]; }
       ++niter;
     }
 #pragma unroll
@@ -1329,6 +1390,7 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
       for (int k = 0; k < 3; ++k) w.s_xpos[k] = 0.0f;
       w.s_xquat[0] = 1.0f; w.s_xquat[1] = w.s_xquat[2] = w.s_xquat[3] = 0.0f;
     }
+    for (int rep = 0; rep < RR_REP_KIN; ++rep) w.kinematics();
     w.kinematics();
     w.template stamp<PROF>(0);
     w.com_pos();
@@ -1391,8 +1453,10 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
         for (int k = 0; k < 9; ++k) w.con_chain[cs][k] = T.con_chain_packed[k * (NCS * RR_LANES) + cs * RR_LANES + ol];
     }
     w.sync();
+    for (int rep = 0; rep < RR_REP_MM; ++rep) w.mass_matrix();
     w.mass_matrix();
     w.template stamp<PROF>(4);
+    for (int rep = 0; rep < RR_REP_FACTOR; ++rep) w.factor(0.0f);
     w.factor(0.0f);
     w.template stamp<PROF>(5);
 #pragma unroll

@@ -245,6 +245,47 @@ def build_kernel_tables(m):
     seq = np.concatenate([sol[::-1], sol], axis=0)              # backward pass rows (deep -> shallow), then forward rows
     pad = (-seq.shape[0]) % PF + PF
     k["k_solve_seq"] = np.concatenate([seq, np.full((pad, W2), -1, np.int32)], axis=0)
+    # ---- atomic-free solve schedule (LDS float atomics cost ~10x a plain read-modify-write on gfx950):
+    #  backward pass (L^-T), level l = dmax..1: GATHER rows -- lane j (an ancestor) adds up L_ij x_i over the dofs i of
+    #  depth l below it (one row per contributor rank), then does ONE plain x_j -= acc;
+    #  forward pass (L^-1), level l = 1..dmax: entry-parallel products L_ij x_j, summed per dof by a DPP wave reduction
+    #  (entries of dof rank r carry r in bits 28..31; an empty slot is exactly -1), written by one lane.
+    Wd = NVS * LANES
+    brow, blev = [], []          # rows [Wd] of (L idx | i << 12), -1 = none ; level boundary flags
+    for l in range(dmax, 0, -1):
+        contrib = [[] for _ in range(nv)]
+        for i in by_level[l]:
+            chain = anc[anc_adr[i]:anc_adr[i + 1]][::-1]
+            for pp in range(1, l + 1):
+                contrib[int(chain[pp])].append((Madr[i] + pp) | (i << 12))
+        T = max(len(c) for c in contrib)
+        for t in range(T):
+            row = np.full(Wd, -1, np.int32)
+            for j in range(nv):
+                if t < len(contrib[j]):
+                    row[j] = contrib[j][t]
+            brow.append(row)
+            blev.append(1 if t == T - 1 else 0)      # last row of the level: apply and hand off
+    frow, fmeta = [], []
+    for l in range(1, dmax + 1):
+        if len(by_level[l]) > 15:
+            raise ValueError("more than 15 dofs on one depth level (4-bit rank field)")
+        ent = []
+        for r, i in enumerate(by_level[l]):
+            chain = anc[anc_adr[i]:anc_adr[i + 1]][::-1]
+            for pp in range(1, l + 1):
+                v = (int(Madr[i]) + pp) | (int(i) << 12) | (int(chain[pp]) << 20) | (r << 28)
+                ent.append(v - (1 << 32) if v >= (1 << 31) else v)     # as a signed 32-bit pattern
+        row = np.full(W2, -1, np.int32)
+        row[:len(ent)] = ent
+        frow.append(row)
+        fmeta.append([len(by_level[l])] + [int(x) for x in by_level[l]] + [0] * (15 - len(by_level[l])))
+    padrow = np.full(Wd, -1, np.int32)
+    k["k_solveb"] = np.stack(brow + [padrow] * PF).astype(np.int32)
+    k["k_solveb_last"] = np.asarray(blev + [0] * PF, np.int32)
+    k["k_solveb_rows"] = np.int32(len(brow))
+    k["k_solvef"] = np.stack(frow + [np.full(W2, -1, np.int32)] * PF).astype(np.int32)
+    k["k_solvef_meta"] = np.asarray(fmeta + [[0] * 16] * PF, np.int32)      # [dmax + PF][16]: n_l, dof ids by rank
     k["k_solve2"] = sol                                        # row l-1: entries (e | i<<12 | j<<20) with depth(i) = l
     frows, flevel = [], []
     for l in range(dmax, 0, -1):
