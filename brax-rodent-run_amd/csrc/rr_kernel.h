@@ -40,7 +40,7 @@ struct RRDims {
   float dt, gx, gy, gz, tolerance, ls_tolerance, meaninertia;
   // LDS offsets (floats)
   int o_qpos, o_qvel, o_act, o_ctrl, o_xpos, o_xquat, o_cinert, o_cdof, o_cvel,
-      o_qM, o_qLD, o_vec, o_x, o_y, o_arm, o_chain, o_warm, o_qact, lds_floats;
+      o_qM, o_qLD, o_vec, o_x, o_y, o_arm, o_chain, o_warm, o_qact, o_base, lds_floats;
   // debug dump offsets (floats)
   int g_xpos, g_xquat, g_xmat, g_com, g_cinert, g_crb, g_cdof, g_cvel, g_cfrc, g_qM, g_qLD, g_dinv, g_bias, g_passive,
       g_actuator, g_smooth, g_qacc_smooth, g_con_dist, g_con_pos, g_con_frame, g_con_D, g_con_aref, g_lim, g_qacc,
@@ -51,7 +51,7 @@ struct RRDims {
 typedef const int __attribute__((address_space(1)))* rr_gi;
 typedef const float __attribute__((address_space(1)))* rr_gf;
 struct RRTables {
-  rr_gi solveb, solveb_last, solvef, solvef_meta, lvl_adr, lvl_body, child, body_i, jnt_i, dof_i, M_ij_k, M_rowadr, tri, mulm, solve_fwd, solve_bwd,
+  rr_gi factor3, factor3_flag, linv, dof_chain, dof_base, lvl_adr, lvl_body, child, body_i, jnt_i, dof_i, M_ij_k, M_rowadr, tri, mulm, solve_fwd, solve_bwd,
       solve_bwd_adr, solve_bwd_level, bwd_steps, body_anc, con_chain_packed, solve2, solve_seq, factor2, factor2_first, con_i, con_chain, jtf;
   rr_gf body_f, jnt_f, dof_f, act_f, con_f, root_mass;
 };
@@ -273,6 +273,7 @@ struct Wave {
   // s_buf reuses xpos|xquat after the contact geometry has been taken.
   float *s_qpos, *s_qvel, *s_act, *s_ctrl, *s_xpos, *s_xquat, *s_cinert, *s_crb, *s_cdof, *s_cvel, *s_cacc,
       *s_cfrc, *s_buf, *s_sc, *s_qM, *s_qLD, *s_vec, *s_x, *s_y, *s_arm, *s_warm, *s_qact;
+  int* s_base;            // Madr + depth per dof (entry (i, j) of a descendant i of j sits at s_base[i] - depth[j])
 
   static constexpr int W = NVS * RR_LANES;
   static constexpr int WC = NCS * RR_LANES;
@@ -312,6 +313,7 @@ struct Wave {
     s_cdof = l + d.o_cdof; s_cvel = l + d.o_cvel; s_qM = l + d.o_qM; s_qLD = l + d.o_qLD;
     s_cacc = s_qLD; s_cfrc = s_qLD + 6 * d.nbody; s_sc = s_qLD; s_buf = s_xpos;
     s_vec = l + d.o_vec; s_x = l + d.o_x; s_y = l + d.o_y; s_arm = l + d.o_arm; s_warm = l + d.o_warm; s_qact = l + d.o_qact;
+    s_base = (int*)(l + d.o_base);
   }
 
   // One wavefront owns the environment: its LDS instructions execute in program order, so a
@@ -688,10 +690,13 @@ struct Wave {
   }
 
   // sparse L'DL in place in s_qLD  [MuJoCo mj_factorM]; damp = dt for the eulerdamp matrix M + dt*diag(damping).
-  // Level-parallel: all dofs k of one depth level are eliminated together -- their rows are final (only deeper dofs
-  // update them) and their rank-1 updates of shared ancestor entries are combined with LDS float atomics.  One table
-  // row (k_factor2) = 64 independent (src_p, src_q, dst, pivot) updates; the next row is prefetched while the current
-  // one executes; a level boundary is a single LDS hand-off.  Rows are scaled by 1/D afterwards.
+  // Level-parallel and ATOMIC-FREE: an LDS float atomic costs ~10x a plain LDS read-modify-write on gfx950 and >1000
+  // cycles with every wave of the CU issuing them.  All dofs k of one depth level are eliminated together (their rows are
+  // final: only deeper dofs update them).  The rank-1 updates of a level are grouped by TARGET entry (k_factor3): a lane
+  // owns one target per group of 64 targets and sums its contributions L_kp L_kq / D_k over the level's dofs k below it,
+  // one table row per contribution rank; the row flagged 1 applies the sum with a plain read-modify-write, the row flagged
+  // 2 closes the level (one LDS hand-off).  The sources of a level are never written by that level, so all of its reads
+  // are independent; table rows are prefetched RR_PF ahead.  Rows are scaled by 1/D afterwards.
   __device__ __forceinline__ void factor(float damp) {
     for (int e = lane; e < D.nM; e += RR_LANES) s_qLD[e] = s_qM[e];
     sync();
@@ -703,26 +708,28 @@ struct Wave {
       }
       sync();
     }
-    // rows are padded to a multiple of RR_PF; a ring of RR_PF rows is kept in flight so the L2 latency of the
-    // table stream is hidden behind RR_PF-1 rows of LDS work
     typedef const unsigned long long __attribute__((address_space(1)))* rr_gu64;
-    rr_gu64 tab = (rr_gu64)T.factor2;
+    rr_gu64 tab = (rr_gu64)T.factor3;
     int2 ring[RR_PF];
     int fring[RR_PF];
 #pragma unroll
-    for (int u = 0; u < RR_PF; ++u) { { const unsigned long long q_ = tab[u * RR_LANES + lane]; ring[u].x = (int)(unsigned)q_; ring[u].y = (int)(q_ >> 32); } fring[u] = g_int(T.factor2_first, u); }
+    for (int u = 0; u < RR_PF; ++u) { { const unsigned long long q_ = tab[u * RR_LANES + lane]; ring[u].x = (int)(unsigned)q_; ring[u].y = (int)(q_ >> 32); } fring[u] = g_int(T.factor3_flag, u); }
+    float acc = 0.0f;
     for (int r0 = 0; r0 < D.nfac; r0 += RR_PF) {
 #pragma unroll
       for (int u = 0; u < RR_PF; ++u) {
         const int2 e = ring[u];
-        const int first = fring[u];
-        if (r0 + RR_PF < D.nfac) { { const unsigned long long q_ = tab[(r0 + RR_PF + u) * RR_LANES + lane]; ring[u].x = (int)(unsigned)q_; ring[u].y = (int)(q_ >> 32); } fring[u] = g_int(T.factor2_first, r0 + RR_PF + u); }
-        if (first) sync();     // updates of the deeper level must have landed
+        const int fl = fring[u];
+        { const unsigned long long q_ = tab[(r0 + RR_PF + u) * RR_LANES + lane]; ring[u].x = (int)(unsigned)q_; ring[u].y = (int)(q_ >> 32); } fring[u] = g_int(T.factor3_flag, r0 + RR_PF + u);
         if (e.x >= 0) {
-          const int a = e.x & 4095, bq = e.x >> 12, dst = e.y & 4095, piv = e.y >> 12;
-          const float tmp = s_qLD[a] * (1.0f / s_qLD[piv]);
-          atomicAdd(s_qLD + dst, -(s_qLD[bq] * tmp));
+          const int a = e.x & 4095, bq = e.x >> 12, piv = e.y >> 12;
+          acc += s_qLD[bq] * (s_qLD[a] * (1.0f / s_qLD[piv]));
         }
+        if (fl & 1) {
+          if (e.y >= 0) s_qLD[e.y & 4095] -= acc;
+          acc = 0.0f;
+        }
+        if (fl & 2) sync();
       }
     }
     sync();
@@ -744,76 +751,90 @@ struct Wave {
     sync();
   }
 
-  // x <- (L' D L)^-1 x  [MuJoCo mj_solveLD], level-parallel and ATOMIC-FREE (an LDS float atomic costs ~10x a plain LDS
-  // read-modify-write on gfx950 and >1000 cycles with every wave of the CU issuing them).  Lane d owns x_d in a register.
-  //  backward (L^-T), deep -> shallow: gather rows -- lane j adds L_ij x_i over the dofs i of the level below it (one
-  //  table row per contributor rank), then x_j -= acc and republishes x_j;
-  //  forward (L^-1), shallow -> deep: one entry-parallel row of products L_ij x_j per level, summed per dof of the level
-  //  by a DPP wave reduction (dof rank in bits 28..31 of the entry) and applied by the owner lane.
-  //  One LDS hand-off per level in each pass; table rows are prefetched one ahead.
-#ifdef RR_EXP_NOLOAD
-#define SOLB(i) ((((i) * 7 + 3) & 1023) | ((((i) * 5) & 63) << 12))
-#define SOLF(i) ((((i) * 7 + 3) & 1023) | ((((i) * 5) & 63) << 20) | (((i) & 1) << 28))
-#else
-#define SOLB(i) g_int(T.solveb, (i))
-#define SOLF(i) g_int(T.solvef, (i))
-#endif
-  __device__ __forceinline__ void ldl_solve(float* x) {
+  // U = L^-1 in place of L (same tree sparsity: U_ij != 0 only for j an ancestor of i).  The triangular solves of
+  // mj_solveLD are chains of ~2*depth dependent LDS hand-offs each, and the step makes 11 of them per factorisation; with
+  // U they become two independent sparse products.  One table row (k_linv) per depth level, shallow -> deep, one lane per
+  // entry (i, p) = (row dof, p-th ancestor):  U_ip = -L_ip - sum_{0<q<p} L_iq U[anc_q(i)][p - q]  (rows of the ancestors
+  // are final; k_M_rowadr gives their addresses).  All sums of a level are taken before any of its entries is replaced.
+  __device__ __forceinline__ void invert() {
     constexpr int W2 = NVS * RR_LANES;
-    float xr[NVS], acc[NVS];
-#pragma unroll
-    for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; xr[s] = x[s]; acc[s] = 0.0f; if (d < D.nv) s_x[d] = x[s]; }
     int en[NVS];
 #pragma unroll
-    for (int s = 0; s < NVS; ++s) en[s] = SOLB(s * RR_LANES + lane);
-    int lastn = g_int(T.solveb_last, 0);
-    sync();
-    for (int r = 0; r < D.nsolb; ++r) {
-      int e[NVS];
-      const int last = lastn;
-#pragma unroll
-      for (int s = 0; s < NVS; ++s) { e[s] = en[s]; en[s] = SOLB((r + 1) * W2 + s * RR_LANES + lane); }
-      lastn = g_int(T.solveb_last, r + 1);
-#pragma unroll
-      for (int s = 0; s < NVS; ++s)
-        if (e[s] >= 0) acc[s] += s_qLD[e[s] & 4095] * s_x[e[s] >> 12];
-      if (last) {
-#pragma unroll
-        for (int s = 0; s < NVS; ++s) {
-          const int d = lane + RR_LANES * s;
-          xr[s] -= acc[s]; acc[s] = 0.0f;
-          if (d < D.nv) s_x[d] = xr[s];
-        }
-        sync();
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; xr[s] *= dinv[s]; if (d < D.nv) s_x[d] = xr[s]; }
-#pragma unroll
-    for (int s = 0; s < NVS; ++s) en[s] = SOLF(s * RR_LANES + lane);
-    sync();
+    for (int s = 0; s < NVS; ++s) en[s] = g_int(T.linv, s * RR_LANES + lane);
     for (int l = 0; l < D.dmax; ++l) {
       int e[NVS];
-      float prod[NVS];
+      float val[NVS];
 #pragma unroll
-      for (int s = 0; s < NVS; ++s) { e[s] = en[s]; en[s] = SOLF((l + 1) * W2 + s * RR_LANES + lane); }
+      for (int s = 0; s < NVS; ++s) { e[s] = en[s]; en[s] = g_int(T.linv, (l + 1) * W2 + s * RR_LANES + lane); }
 #pragma unroll
-      for (int s = 0; s < NVS; ++s) prod[s] = e[s] != -1 ? s_qLD[e[s] & 4095] * s_x[(e[s] >> 20) & 255] : 0.0f;
-      const int nl = g_int(T.solvef_meta, 16 * l);
-      for (int r = 0; r < nl; ++r) {
-        float v = 0.0f;
-#pragma unroll
-        for (int s = 0; s < NVS; ++s) v += (e[s] != -1 && (int)((unsigned)e[s] >> 28) == r) ? prod[s] : 0.0f;
-        v = wave_sum(v);
-        const int i = g_int(T.solvef_meta, 16 * l + 1 + r);     // wave-uniform dof id of rank r
-#pragma unroll
-        for (int s = 0; s < NVS; ++s)
-          if (lane + RR_LANES * s == i) { xr[s] -= v; s_x[i] = xr[s]; }
+      for (int s = 0; s < NVS; ++s) {
+        val[s] = 0.0f;
+        if (e[s] >= 0) {
+          const int adr = e[s] & 4095, p = e[s] >> 12, mi = adr - p;
+          float sm = s_qLD[adr];
+#pragma unroll 4
+          for (int q = 1; q < p; ++q) sm += s_qLD[mi + q] * s_qLD[g_int(T.M_rowadr, mi + q) + p - q];
+          val[s] = -sm;
+        }
       }
       sync();
+#pragma unroll
+      for (int s = 0; s < NVS; ++s)
+        if (e[s] >= 0) s_qLD[e[s] & 4095] = val[s];
+      sync();
+    }
+  }
+
+  // x <- (L' D L)^-1 x = U D^-1 U' x  [MuJoCo mj_solveLD] with the explicit inverse factor U (see invert): no dependent
+  // chain, no atomics.  U' x: lane j gathers over its descendants i (a contiguous DFS range), entry (i, j) sits at
+  // base[i] - depth[j];  U y: lane i walks its ancestor chain (ids packed 4 per register, loaded per call), entry (i, p)
+  // at Madr[i] + p.  Lane d owns x_d.
+  __device__ __forceinline__ void ldl_solve(float* x) {
+    constexpr int W = NVS * RR_LANES;
+    int ch[NVS][9];
+    {
+      const int ol = opaque(lane);
+#pragma unroll
+      for (int s = 0; s < NVS; ++s)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) ch[s][k] = g_int(T.dof_chain, k * W + s * RR_LANES + ol);
     }
 #pragma unroll
-    for (int s = 0; s < NVS; ++s) x[s] = xr[s];
+    for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; if (d < D.nv) s_x[d] = x[s]; }
+    sync();
+    float y[NVS];
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) {
+      const int j = lane + RR_LANES * s;
+      float acc = x[s];
+      if (j < D.nv) {
+        const int dj = opaque(dofc0[s]) & 255, last = opaque(dofc1[s]) >> 16;
+#pragma unroll 4
+        for (int i = j + 1; i <= last; ++i) acc += s_qLD[s_base[i] - dj] * s_x[i];
+      }
+      y[s] = acc * dinv[s];
+    }
+    sync();
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; if (d < D.nv) s_x[d] = y[s]; }
+    sync();
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) {
+      const int d = lane + RR_LANES * s;
+      float acc = y[s];
+      const int depth = d < D.nv ? (opaque(dofc0[s]) & 255) : 0, madr = opaque(dofc1[s]) & 0xFFFF;
+#pragma unroll
+      for (int p0 = 0; p0 < 36; p0 += 4) {
+        if (__any(p0 < depth)) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u + 1;
+            if (p <= depth) acc += s_qLD[madr + p] * s_x[(ch[s][p0 >> 2] >> (8 * u)) & 255];
+          }
+        }
+      }
+      x[s] = acc;
+    }
   }
 
   // y = M * s_vec (s_vec must be visible).  Entry-parallel: lane owns matrix entries e = lane + 64 it (row/col ids
@@ -1280,6 +1301,7 @@ struct Wave {
   // ---------------------------------------------------------------- A-8 euler (+eulerdamp) and position integration
   __device__ __forceinline__ void euler() {
     factor(D.dt);
+    invert();
     float qa[NVS];
 #pragma unroll
     for (int s = 0; s < NVS; ++s) qa[s] = qfrc_smooth[s] + qfrc_con[s];
@@ -1355,7 +1377,7 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
     }
     w.qacc[s] = w.Ma[s] = w.grad[s] = w.Mgrad[s] = w.search[s] = w.mv[s] = w.qfrc_con[s] = 0.0f;
   }
-  for (int i = lane; i < D.nv; i += RR_LANES) w.s_arm[i] = T.dof_f[16 * i];
+  for (int i = lane; i < D.nv; i += RR_LANES) { w.s_arm[i] = T.dof_f[16 * i]; w.s_base[i] = T.dof_base[i]; }
   if (lane == 0) {  // world body entries that no phase overwrites
     for (int k = 0; k < 6; ++k) w.s_cvel[k] = 0.0f;
     for (int k = 0; k < 10; ++k) w.s_cinert[k] = 0.0f;
@@ -1458,13 +1480,15 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
     w.template stamp<PROF>(4);
     for (int rep = 0; rep < RR_REP_FACTOR; ++rep) w.factor(0.0f);
     w.factor(0.0f);
+    if (dg) for (int e = lane; e < D.nM; e += RR_LANES) dg[D.g_qLD + e] = w.s_qLD[e];
+    w.invert();
     w.template stamp<PROF>(5);
 #pragma unroll
     for (int s = 0; s < NVS; ++s) w.qacc_smooth[s] = w.qfrc_smooth[s];
     w.ldl_solve(w.qacc_smooth);
     w.template stamp<PROF>(6);
     if (dg) {
-      for (int e = lane; e < D.nM; e += RR_LANES) { dg[D.g_qM + e] = w.s_qM[e]; dg[D.g_qLD + e] = w.s_qLD[e]; }
+      for (int e = lane; e < D.nM; e += RR_LANES) dg[D.g_qM + e] = w.s_qM[e];
 #pragma unroll
       for (int s = 0; s < NVS; ++s) {
         const int d = lane + RR_LANES * s;

@@ -18,6 +18,11 @@ def asset_path(name: str) -> str:
     return os.path.join(ASSET_DIR, f"{name}.rrm")
 
 
+def _compiler_mtime() -> float:
+    from . import ktables
+    return max(os.path.getmtime(mjcf.__file__), os.path.getmtime(ktables.__file__))
+
+
 def build_assets(xml_dir: str, names=MODELS, force: bool = False):
     os.makedirs(ASSET_DIR, exist_ok=True)
     built = []
@@ -25,7 +30,7 @@ def build_assets(xml_dir: str, names=MODELS, force: bool = False):
         src, dst = os.path.join(xml_dir, f"{n}.xml"), asset_path(n)
         if not os.path.exists(src):
             continue
-        if force or not os.path.exists(dst) or os.path.getmtime(dst) < os.path.getmtime(mjcf.__file__):
+        if force or not os.path.exists(dst) or os.path.getmtime(dst) < _compiler_mtime():
             mjcf.save_blob(mjcf.compile_mjcf(src), dst)
             built.append(dst)
     return built

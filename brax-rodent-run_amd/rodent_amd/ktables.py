@@ -309,6 +309,64 @@ def build_kernel_tables(m):
     k["k_factor2_first"] = np.asarray(flevel, np.int32)          # row opens a new level
     k["k_factor2_rows"] = np.int32(len(frows) - PF)
 
+    # ---- atomic-free factorisation: per depth level (deep -> shallow) the rank-1 updates are grouped by TARGET entry.
+    # A lane owns one target per group of 64 targets and accumulates its contributions L_kp L_kq / D_k over the dofs k of
+    # the level below it, one table row per contribution rank; the row flagged 1 applies the sum with a plain
+    # read-modify-write, the row flagged 2 also closes the level (LDS hand-off).  Sources are rows k of the level being
+    # eliminated, which no update of that level writes, so every read of a level is independent of its writes.
+    g_rows, g_flag = [], []
+    for l in range(dmax, 0, -1):
+        tgt = {}
+        for kk in by_level[l]:
+            chain = anc[anc_adr[kk]:anc_adr[kk + 1]][::-1]
+            for q in range(1, l + 1):
+                for p in range(1, q + 1):
+                    dst = int(Madr[int(chain[p])] + (q - p))
+                    tgt.setdefault(dst, []).append((int(Madr[kk] + p) | (int(Madr[kk] + q) << 12), dst | (int(Madr[kk]) << 12)))
+        order = sorted(tgt, key=lambda d_: (-len(tgt[d_]), d_))          # equal multiplicities share a group
+        for g0 in range(0, len(order), LANES):
+            grp = order[g0:g0 + LANES]
+            mult = max(len(tgt[d_]) for d_ in grp)
+            for t in range(mult):
+                row = np.full((LANES, 2), -1, np.int32)
+                for ln, d_ in enumerate(grp):
+                    if t < len(tgt[d_]):
+                        row[ln] = tgt[d_][t]
+                    else:
+                        row[ln] = (-1, d_ | (0 << 12))                   # no contribution on this rank; target kept
+                g_rows.append(row)
+                g_flag.append(1 if t == mult - 1 else 0)
+        g_flag[-1] = 3
+    k["k_factor3_rows"] = np.int32(len(g_rows))
+    while len(g_rows) % PF or not g_rows:
+        g_rows.append(np.full((LANES, 2), -1, np.int32)); g_flag.append(0)
+    g_rows += [np.full((LANES, 2), -1, np.int32)] * PF; g_flag += [0] * PF
+    k["k_factor3"] = np.stack(g_rows).astype(np.int32)           # [R + PF][64][2]: (a | bq<<12, dst | piv<<12)
+    k["k_factor3_flag"] = np.asarray(g_flag, np.int32)
+
+    # ---- explicit inverse U = L^-1 (same tree sparsity as L): one table row per depth level, shallow -> deep, one lane
+    # per entry (i, p): adr | p << 12 with adr = Madr[i] + p.  U_ip = -L_ip - sum_{q<p} L_iq U[anc_q(i)][p-q], the row
+    # address of anc_q(i) is k_M_rowadr[Madr[i] + q].
+    irows = []
+    for l in range(1, dmax + 1):
+        ent = [(int(Madr[i]) + pp) | (pp << 12) for i in by_level[l] for pp in range(1, l + 1)]
+        if len(ent) > W2:
+            raise ValueError("more than %d L entries on one depth level" % W2)
+        row = np.full(W2, -1, np.int32)
+        row[:len(ent)] = ent
+        irows.append(row)
+    k["k_linv"] = np.stack(irows + [np.full(W2, -1, np.int32)] * PF).astype(np.int32)     # [dmax + PF][W2]
+    # ancestor dof ids of every dof, nearest first, 4 per int: [9][NVS * 64]
+    if dmax > 36:
+        raise ValueError("dof depth above 36")
+    dch = np.zeros((9, Wd), np.int64)
+    for i in range(nv):
+        chain = anc[anc_adr[i]:anc_adr[i + 1]][::-1]
+        for pp in range(1, len(chain)):
+            dch[(pp - 1) >> 2, i] |= int(chain[pp]) << (8 * ((pp - 1) & 3))
+    k["k_dof_chain"] = (dch & 0xFFFFFFFF).astype(np.uint32).view(np.int32).reshape(9, Wd)
+    k["k_dof_base"] = (Madr[:nv] + ddepth[:nv]).astype(np.int32)   # entry (i, j) of a descendant i sits at base[i] - depth[j]
+
     # ---- contacts
     WC = NCS * LANES
     g2 = m["con_geom2"]

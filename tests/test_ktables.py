@@ -47,57 +47,83 @@ def test_mulm_table(model_and_state):
 
 
 def kernel_factor(m, qM):
-    """numpy restatement of Wave::factor (pair table)."""
+    """numpy restatement of Wave::factor: per level, gather rows by target entry (k_factor3), plain read-modify-write on
+    the rows flagged 1, level hand-off on the rows flagged 2; then the row scaling by 1/D."""
     nv = int(m["nv"])
     L = qM.copy()
-    depth, Madr = m["k_dof_i"][:, 3], m["k_dof_i"][:, 4]
-    tri, rowadr = m["k_tri"], m["k_M_rowadr"]
-    for k in range(nv - 1, -1, -1):
-        dk = depth[k]
-        if dk == 0:
-            continue
-        Mkk = Madr[k]
-        dkk = L[Mkk]
-        npairs = dk * (dk + 1) // 2
-        pq = tri[:npairs]
-        p, q = pq & 255, pq >> 8
-        tmp = L[Mkk + p] / dkk
-        adr = rowadr[Mkk + p] + (q - p)
-        assert len(set(adr.tolist())) == npairs          # no two lanes update one address
-        L[adr] -= L[Mkk + q] * tmp
-        L[Mkk + 1:Mkk + dk + 1] /= dkk
-    return L, 1.0 / L[Madr]
+    tab, flag, R = m["k_factor3"], m["k_factor3_flag"], int(m["k_factor3_rows"])
+    acc = np.zeros(LANES)
+    dst = np.full(LANES, -1)
+    written_in_level, read_in_level = set(), set()
+    for r in range(R):
+        e = tab[r]
+        ok = e[:, 0] >= 0
+        a, bq, piv = e[ok, 0] & 4095, e[ok, 0] >> 12, e[ok, 1] >> 12
+        read_in_level.update(a.tolist()); read_in_level.update(bq.tolist()); read_in_level.update(piv.tolist())
+        acc[ok] += L[a] / L[piv] * L[bq]
+        has = e[:, 1] >= 0
+        assert np.all(dst[has] == -1) or np.all(dst[has] == (e[has, 1] & 4095))   # one target per lane within a group
+        dst[has] = e[has, 1] & 4095
+        if flag[r] & 1:
+            t = dst[dst >= 0]
+            assert len(set(t.tolist())) == len(t)                                # plain RMW: no two lanes share a target
+            assert not (set(t.tolist()) & written_in_level)                      # one RMW per target and level
+            written_in_level.update(t.tolist())
+            L[t] -= acc[dst >= 0]
+            acc[:] = 0.0
+            dst[:] = -1
+        if flag[r] & 2:
+            assert not (written_in_level & read_in_level)                        # reads of a level never see its writes
+            written_in_level, read_in_level = set(), set()
+    assert np.all(acc == 0.0) and np.all(tab[R:] == -1)
+    Madr = m["k_dof_i"][:, 4]
+    dinv = 1.0 / L[Madr]
+    ij = m["k_M_ij"]
+    i, j = ij & 0xFFFF, ij >> 16
+    off = i != j
+    L[off] *= dinv[i[off]]
+    return L, dinv
 
 
-def kernel_solve(m, L, dinv, x):
-    """numpy restatement of Wave::ldl_solve (level-synchronous)."""
-    nv = int(m["nv"])
-    depth = m["k_dof_i"][:, 3]
-    dmax = int(depth.max())
-    W = m["k_solve_fwd"].shape[1]
-    xr = np.zeros(W)
-    xr[:nv] = x
-    dep = np.full(W, -1)
-    dep[:nv] = depth
-    sx = np.zeros(W)
-    bwd, adr = m["k_solve_bwd"], m["k_solve_bwd_adr"]
-    for li in range(dmax):
-        level = dmax - li
-        sel = dep == level
-        sx[sel] = xr[sel]
-        for r in range(adr[li], adr[li + 1]):
-            e = bwd[r]
-            ok = e >= 0
-            xr[ok] -= L[e[ok] >> 8] * sx[e[ok] & 255]
-    xr[:nv] *= dinv
-    fwd = m["k_solve_fwd"]
+def kernel_invert(m, L):
+    """numpy restatement of Wave::invert: U = L^-1 in place, one k_linv row per depth level (read phase, then write)."""
+    U = L.copy()
+    rowadr = m["k_M_rowadr"]
+    tab = m["k_linv"]
+    dmax = int(m["k_dof_i"][:, 3].max())
     for l in range(dmax):
-        sel = dep == l
-        sx[sel] = xr[sel]
-        e = fwd[l]
-        ok = e >= 0
-        xr[ok] -= L[e[ok] >> 8] * sx[e[ok] & 255]
-    return xr[:nv]
+        e = tab[l][tab[l] >= 0]
+        adr, p = e & 4095, e >> 12
+        val = np.zeros(len(e))
+        for n in range(len(e)):
+            mi = adr[n] - p[n]
+            sm = U[adr[n]]
+            for q in range(1, p[n]):
+                sm += U[mi + q] * U[rowadr[mi + q] + p[n] - q]
+            val[n] = -sm
+        U[adr] = val
+    assert np.all(tab[dmax:] == -1)
+    return U
+
+
+def kernel_solve(m, U, dinv, b):
+    """numpy restatement of Wave::ldl_solve with the explicit inverse: x = U D^-1 U' b (unit diagonal implied).
+    U' b gathers over the DFS range of descendants (entry of (i, j) at base[i] - depth[j]); U y walks the ancestor chain."""
+    nv = int(m["nv"])
+    di = m["k_dof_i"]
+    depth, Madr, last = di[:, 3], di[:, 4], di[:, 10]
+    base, chain = m["k_dof_base"], m["k_dof_chain"]
+    y = b.copy()
+    for j in range(nv):
+        for i in range(j + 1, last[j] + 1):
+            y[j] += U[base[i] - depth[j]] * b[i]
+    y *= dinv
+    x = y.copy()
+    for i in range(nv):
+        for p in range(1, depth[i] + 1):
+            a = (int(chain[(p - 1) >> 2, i]) >> (8 * ((p - 1) & 3))) & 255
+            x[i] += U[Madr[i] + p] * y[a]
+    return x
 
 
 def test_factor_and_solve_tables(model_and_state):
@@ -106,9 +132,10 @@ def test_factor_and_solve_tables(model_and_state):
     L, dinv = kernel_factor(m, qM)
     np.testing.assert_allclose(L, qLD, rtol=1e-9, atol=1e-16)
     np.testing.assert_allclose(dinv, d.get("qLDiagInv"), rtol=1e-9)
+    U = kernel_invert(m, L)
     Md = dense_from_sparse(m, qM)
     b = np.random.default_rng(2).normal(size=M.nv)
-    x = kernel_solve(m, L, dinv, b)
+    x = kernel_solve(m, U, dinv, b)
     np.testing.assert_allclose(Md @ x, b, rtol=1e-7, atol=1e-9)
 
 
