@@ -36,7 +36,7 @@
 
 struct RRDims {
   int nq, nv, nu, nbody, njnt, nM, ncon, nlevel, dmax, nroot;
-  int T_mulm, T_jtf, T_chain, obs_dim, iterations, ls_iterations, nJ, ntri, nbwd, nfac, nround, nchain, nment, nsolb;
+  int T_mulm, T_jtf, T_chain, obs_dim, iterations, ls_iterations, nJ, ntri, nbwd, nfac, nround, nchain, nment, ninv;
   float dt, gx, gy, gz, tolerance, ls_tolerance, meaninertia;
   // LDS offsets (floats)
   int o_qpos, o_qvel, o_act, o_ctrl, o_xpos, o_xquat, o_cinert, o_cdof, o_cvel,
@@ -51,7 +51,7 @@ struct RRDims {
 typedef const int __attribute__((address_space(1)))* rr_gi;
 typedef const float __attribute__((address_space(1)))* rr_gf;
 struct RRTables {
-  rr_gi factor3, factor3_flag, linv, dof_chain, dof_base, lvl_adr, lvl_body, child, body_i, jnt_i, dof_i, M_ij_k, M_rowadr, tri, mulm, solve_fwd, solve_bwd,
+  rr_gi factor3, factor3_flag, linv, linv_flag, dof_chain, dof_base, lvl_adr, lvl_body, child, body_i, jnt_i, dof_i, M_ij_k, M_rowadr, tri, mulm, solve_fwd, solve_bwd,
       solve_bwd_adr, solve_bwd_level, bwd_steps, body_anc, con_chain_packed, solve2, solve_seq, factor2, factor2_first, con_i, con_chain, jtf;
   rr_gf body_f, jnt_f, dof_f, act_f, con_f, root_mass;
 };
@@ -258,6 +258,9 @@ __device__ __forceinline__ BodyC load_bodyc(const RRTables& T, int b, int nbody)
 #endif
 #ifndef RR_REP_MM
 #define RR_REP_MM 0
+#endif
+#ifndef RR_REP_INV
+#define RR_REP_INV 0
 #endif
 #ifndef RR_REP_KIN
 #define RR_REP_KIN 0
@@ -689,14 +692,59 @@ struct Wave {
     sync();
   }
 
+  // Executor of the level schedules of the factorisation and the inversion (rodent_amd/ktables.py pack_levels).  A table
+  // row is 64 independent operations (src1 | src2 << 12, dst | piv << 12) on s_qLD; a lane accumulates
+  // src2 * src1 [/ piv] over consecutive rows and, on a row flagged 1, stores dst = dst_old - sum (plain read-modify-write:
+  // within a level every dst belongs to one lane and is written once, and no source of a level is written by that level).
+  // The LDS reads of a block of RR_PF rows -- sources and old target values -- are therefore issued together, one LDS
+  // round trip per block instead of two per row; levels end at block ends (flag 2: one LDS hand-off).  ATOMIC-FREE: an LDS
+  // float atomic costs ~10x a plain read-modify-write on gfx950 and >1000 cycles with every wave of the CU issuing them.
+  // Rows are prefetched one block ahead (8-byte global loads).
+  template <bool DIV>
+  __device__ __forceinline__ void run_levels(rr_gi table, rr_gi flags, int nrows) {
+    typedef const unsigned long long __attribute__((address_space(1)))* rr_gu64;
+    rr_gu64 tab = (rr_gu64)table;
+    int2 ring[RR_PF];
+#pragma unroll
+    for (int u = 0; u < RR_PF; ++u) { const unsigned long long q_ = tab[u * RR_LANES + lane]; ring[u].x = (int)(unsigned)q_; ring[u].y = (int)(q_ >> 32); }
+    int fw = g_int(flags, 0);
+    float acc = 0.0f;
+    for (int r0 = 0; r0 < nrows; r0 += RR_PF) {
+      int2 e[RR_PF];
+      const int word = fw;
+#pragma unroll
+      for (int u = 0; u < RR_PF; ++u) {
+        e[u] = ring[u];
+        const unsigned long long q_ = tab[(r0 + RR_PF + u) * RR_LANES + lane];
+        ring[u].x = (int)(unsigned)q_; ring[u].y = (int)(q_ >> 32);
+      }
+      fw = g_int(flags, r0 / RR_PF + 1);
+      float va[RR_PF], vb[RR_PF], vp[RR_PF], vo[RR_PF];
+#pragma unroll
+      for (int u = 0; u < RR_PF; ++u) {   // empty operations read entry 0 (the diagonal of dof 0, non-zero) and are masked below
+        const int x0 = e[u].x < 0 ? 0 : e[u].x, y0 = e[u].y < 0 ? 0 : e[u].y;
+        va[u] = s_qLD[x0 & 4095]; vb[u] = s_qLD[x0 >> 12];
+        vp[u] = DIV ? s_qLD[y0 >> 12] : 1.0f;
+        vo[u] = s_qLD[y0 & 4095];
+      }
+#pragma unroll
+      for (int u = 0; u < RR_PF; ++u) {
+        const float prod = DIV ? vb[u] * (va[u] * (1.0f / vp[u])) : vb[u] * va[u];
+        acc += e[u].x >= 0 ? prod : 0.0f;
+        if ((word >> (2 * u)) & 1) {
+          if (e[u].y >= 0) s_qLD[e[u].y & 4095] = vo[u] - acc;
+          acc = 0.0f;
+        }
+      }
+      if ((word >> (2 * (RR_PF - 1))) & 2) sync();
+    }
+  }
+
   // sparse L'DL in place in s_qLD  [MuJoCo mj_factorM]; damp = dt for the eulerdamp matrix M + dt*diag(damping).
-  // Level-parallel and ATOMIC-FREE: an LDS float atomic costs ~10x a plain LDS read-modify-write on gfx950 and >1000
-  // cycles with every wave of the CU issuing them.  All dofs k of one depth level are eliminated together (their rows are
-  // final: only deeper dofs update them).  The rank-1 updates of a level are grouped by TARGET entry (k_factor3): a lane
-  // owns one target per group of 64 targets and sums its contributions L_kp L_kq / D_k over the level's dofs k below it,
-  // one table row per contribution rank; the row flagged 1 applies the sum with a plain read-modify-write, the row flagged
-  // 2 closes the level (one LDS hand-off).  The sources of a level are never written by that level, so all of its reads
-  // are independent; table rows are prefetched RR_PF ahead.  Rows are scaled by 1/D afterwards.
+  // Level-parallel: all dofs k of one depth level are eliminated together (their rows are final: only deeper dofs update
+  // them).  The rank-1 updates of a level are grouped by TARGET entry (k_factor3): a lane owns one target per group of 64
+  // targets and sums its contributions L_kp L_kq / D_k over the level's dofs k below it, one table row per contribution
+  // rank.  Rows are scaled by 1/D afterwards.
   __device__ __forceinline__ void factor(float damp) {
     for (int e = lane; e < D.nM; e += RR_LANES) s_qLD[e] = s_qM[e];
     sync();
@@ -708,30 +756,7 @@ struct Wave {
       }
       sync();
     }
-    typedef const unsigned long long __attribute__((address_space(1)))* rr_gu64;
-    rr_gu64 tab = (rr_gu64)T.factor3;
-    int2 ring[RR_PF];
-    int fring[RR_PF];
-#pragma unroll
-    for (int u = 0; u < RR_PF; ++u) { { const unsigned long long q_ = tab[u * RR_LANES + lane]; ring[u].x = (int)(unsigned)q_; ring[u].y = (int)(q_ >> 32); } fring[u] = g_int(T.factor3_flag, u); }
-    float acc = 0.0f;
-    for (int r0 = 0; r0 < D.nfac; r0 += RR_PF) {
-#pragma unroll
-      for (int u = 0; u < RR_PF; ++u) {
-        const int2 e = ring[u];
-        const int fl = fring[u];
-        { const unsigned long long q_ = tab[(r0 + RR_PF + u) * RR_LANES + lane]; ring[u].x = (int)(unsigned)q_; ring[u].y = (int)(q_ >> 32); } fring[u] = g_int(T.factor3_flag, r0 + RR_PF + u);
-        if (e.x >= 0) {
-          const int a = e.x & 4095, bq = e.x >> 12, piv = e.y >> 12;
-          acc += s_qLD[bq] * (s_qLD[a] * (1.0f / s_qLD[piv]));
-        }
-        if (fl & 1) {
-          if (e.y >= 0) s_qLD[e.y & 4095] -= acc;
-          acc = 0.0f;
-        }
-        if (fl & 2) sync();
-      }
-    }
+    run_levels<true>(T.factor3, T.factor3_flag, D.nfac);
     sync();
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
@@ -751,42 +776,15 @@ struct Wave {
     sync();
   }
 
-  // U = L^-1 in place of L (same tree sparsity: U_ij != 0 only for j an ancestor of i).  The triangular solves of
-  // mj_solveLD are chains of ~2*depth dependent LDS hand-offs each, and the step makes 11 of them per factorisation; with
-  // U they become two independent sparse products.  One table row (k_linv) per depth level, shallow -> deep, one lane per
-  // entry (i, p) = (row dof, p-th ancestor):  U_ip = -L_ip - sum_{0<q<p} L_iq U[anc_q(i)][p - q]  (rows of the ancestors
-  // are final; k_M_rowadr gives their addresses).  All sums of a level are taken before any of its entries is replaced.
-  __device__ __forceinline__ void invert() {
-    constexpr int W2 = NVS * RR_LANES;
-    int en[NVS];
-#pragma unroll
-    for (int s = 0; s < NVS; ++s) en[s] = g_int(T.linv, s * RR_LANES + lane);
-    for (int l = 0; l < D.dmax; ++l) {
-      int e[NVS];
-      float val[NVS];
-#pragma unroll
-      for (int s = 0; s < NVS; ++s) { e[s] = en[s]; en[s] = g_int(T.linv, (l + 1) * W2 + s * RR_LANES + lane); }
-#pragma unroll
-      for (int s = 0; s < NVS; ++s) {
-        val[s] = 0.0f;
-        if (e[s] >= 0) {
-          const int adr = e[s] & 4095, p = e[s] >> 12, mi = adr - p;
-          float sm = s_qLD[adr];
-#pragma unroll 4
-          for (int q = 1; q < p; ++q) sm += s_qLD[mi + q] * s_qLD[g_int(T.M_rowadr, mi + q) + p - q];
-          val[s] = -sm;
-        }
-      }
-      sync();
-#pragma unroll
-      for (int s = 0; s < NVS; ++s)
-        if (e[s] >= 0) s_qLD[e[s] & 4095] = val[s];
-      sync();
-    }
-  }
+  // W = I - L^-1 (strictly lower part) in place of L: L^-1 has the tree sparsity of L (non-zero only for j an ancestor of
+  // i).  The triangular solves of mj_solveLD are chains of ~2*depth dependent LDS hand-offs each and the step makes 11
+  // of them per factorisation; with W they become two independent sparse products (ldl_solve).  Gauss-Jordan by depth
+  // levels, shallow -> deep (k_linv): when the dofs k of a level are processed every descendant row i does
+  // W_ia -= W_ik W_ka over the strict ancestors a of k; W_ik still holds L_ik (only deeper levels write it), row k is final.
+  __device__ __forceinline__ void invert() { run_levels<false>(T.linv, T.linv_flag, D.ninv); }
 
-  // x <- (L' D L)^-1 x = U D^-1 U' x  [MuJoCo mj_solveLD] with the explicit inverse factor U (see invert): no dependent
-  // chain, no atomics.  U' x: lane j gathers over its descendants i (a contiguous DFS range), entry (i, j) sits at
+  // x <- (L' D L)^-1 x = U D^-1 U' x  [MuJoCo mj_solveLD] with the explicit inverse factor U = I - W (see invert): no
+  // dependent chain, no atomics.  U' x: lane j gathers over its descendants i (a contiguous DFS range), entry (i, j) sits at
   // base[i] - depth[j];  U y: lane i walks its ancestor chain (ids packed 4 per register, loaded per call), entry (i, p)
   // at Madr[i] + p.  Lane d owns x_d.
   __device__ __forceinline__ void ldl_solve(float* x) {
@@ -810,7 +808,7 @@ struct Wave {
       if (j < D.nv) {
         const int dj = opaque(dofc0[s]) & 255, last = opaque(dofc1[s]) >> 16;
 #pragma unroll 4
-        for (int i = j + 1; i <= last; ++i) acc += s_qLD[s_base[i] - dj] * s_x[i];
+        for (int i = j + 1; i <= last; ++i) acc -= s_qLD[s_base[i] - dj] * s_x[i];
       }
       y[s] = acc * dinv[s];
     }
@@ -829,7 +827,7 @@ struct Wave {
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int p = p0 + u + 1;
-            if (p <= depth) acc += s_qLD[madr + p] * s_x[(ch[s][p0 >> 2] >> (8 * u)) & 255];
+            if (p <= depth) acc -= s_qLD[madr + p] * s_x[(ch[s][p0 >> 2] >> (8 * u)) & 255];
           }
         }
       }
@@ -1135,6 +1133,7 @@ struct Wave {
 #pragma unroll
       for (int s = 0; s < NVS; ++s) Ma[s] = qfrc_smooth[s];
     } else {
+      for (int rep = 0; rep < RR_REP_MULM; ++rep) mul_m(Ma);
       mul_m(Ma);
     }
     cost = INFINITY; prev_cost = 0.0f;
@@ -1481,6 +1480,7 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
     for (int rep = 0; rep < RR_REP_FACTOR; ++rep) w.factor(0.0f);
     w.factor(0.0f);
     if (dg) for (int e = lane; e < D.nM; e += RR_LANES) dg[D.g_qLD + e] = w.s_qLD[e];
+    for (int rep = 0; rep < RR_REP_INV; ++rep) w.invert();
     w.invert();
     w.template stamp<PROF>(5);
 #pragma unroll

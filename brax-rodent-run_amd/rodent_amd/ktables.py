@@ -309,12 +309,36 @@ def build_kernel_tables(m):
     k["k_factor2_first"] = np.asarray(flevel, np.int32)          # row opens a new level
     k["k_factor2_rows"] = np.int32(len(frows) - PF)
 
-    # ---- atomic-free factorisation: per depth level (deep -> shallow) the rank-1 updates are grouped by TARGET entry.
-    # A lane owns one target per group of 64 targets and accumulates its contributions L_kp L_kq / D_k over the dofs k of
-    # the level below it, one table row per contribution rank; the row flagged 1 applies the sum with a plain
-    # read-modify-write, the row flagged 2 also closes the level (LDS hand-off).  Sources are rows k of the level being
-    # eliminated, which no update of that level writes, so every read of a level is independent of its writes.
-    g_rows, g_flag = [], []
+    # ---- atomic-free factorisation and inversion schedules.  Both are lists of LEVELS; a level is a list of table rows
+    # of 64 independent operations (src1 | src2 << 12, dst | piv << 12) whose sources are never written inside the level,
+    # so the kernel issues the LDS reads of RR_PF rows (one block) together.  Levels are padded to whole blocks; one flag
+    # word per block carries 2 bits per row: 1 = apply the lane's accumulated sum to dst, 2 = level ends (LDS hand-off).
+    def pack_levels(levels):
+        rows, flags = [], []
+        for lv in levels:
+            if not lv:
+                continue
+            lv = list(lv)
+            while len(lv) % PF:
+                lv.append((np.full((LANES, 2), -1, np.int32), 0))
+            for b0 in range(0, len(lv), PF):
+                word = 0
+                for u in range(PF):
+                    row, fl = lv[b0 + u]
+                    rows.append(row)
+                    word |= fl << (2 * u)
+                if b0 + PF == len(lv):
+                    word |= 2 << (2 * (PF - 1))
+                flags.append(word)
+        nrows = len(rows)
+        rows += [np.full((LANES, 2), -1, np.int32)] * PF          # slack block the ring may prefetch
+        flags += [0]
+        return np.stack(rows).astype(np.int32), np.asarray(flags, np.int32), np.int32(nrows)
+
+    # factorisation [MuJoCo mj_factorM], deep -> shallow: the rank-1 updates of a level are grouped by TARGET entry.  A lane
+    # owns one target per group of 64 targets and accumulates its contributions L_kp L_kq / D_k over the dofs k of the level
+    # below it, one row per contribution rank; the last rank applies the sum with a plain read-modify-write.
+    levels = []
     for l in range(dmax, 0, -1):
         tgt = {}
         for kk in by_level[l]:
@@ -324,38 +348,38 @@ def build_kernel_tables(m):
                     dst = int(Madr[int(chain[p])] + (q - p))
                     tgt.setdefault(dst, []).append((int(Madr[kk] + p) | (int(Madr[kk] + q) << 12), dst | (int(Madr[kk]) << 12)))
         order = sorted(tgt, key=lambda d_: (-len(tgt[d_]), d_))          # equal multiplicities share a group
+        lv = []
         for g0 in range(0, len(order), LANES):
             grp = order[g0:g0 + LANES]
             mult = max(len(tgt[d_]) for d_ in grp)
             for t in range(mult):
                 row = np.full((LANES, 2), -1, np.int32)
                 for ln, d_ in enumerate(grp):
-                    if t < len(tgt[d_]):
-                        row[ln] = tgt[d_][t]
-                    else:
-                        row[ln] = (-1, d_ | (0 << 12))                   # no contribution on this rank; target kept
-                g_rows.append(row)
-                g_flag.append(1 if t == mult - 1 else 0)
-        g_flag[-1] = 3
-    k["k_factor3_rows"] = np.int32(len(g_rows))
-    while len(g_rows) % PF or not g_rows:
-        g_rows.append(np.full((LANES, 2), -1, np.int32)); g_flag.append(0)
-    g_rows += [np.full((LANES, 2), -1, np.int32)] * PF; g_flag += [0] * PF
-    k["k_factor3"] = np.stack(g_rows).astype(np.int32)           # [R + PF][64][2]: (a | bq<<12, dst | piv<<12)
-    k["k_factor3_flag"] = np.asarray(g_flag, np.int32)
+                    row[ln] = tgt[d_][t] if t < len(tgt[d_]) else (-1, d_)   # no contribution on this rank; target kept
+                lv.append((row, 1 if t == mult - 1 else 0))
+        levels.append(lv)
+    k["k_factor3"], k["k_factor3_flag"], k["k_factor3_rows"] = pack_levels(levels)
 
-    # ---- explicit inverse U = L^-1 (same tree sparsity as L): one table row per depth level, shallow -> deep, one lane
-    # per entry (i, p): adr | p << 12 with adr = Madr[i] + p.  U_ip = -L_ip - sum_{q<p} L_iq U[anc_q(i)][p-q], the row
-    # address of anc_q(i) is k_M_rowadr[Madr[i] + q].
-    irows = []
-    for l in range(1, dmax + 1):
-        ent = [(int(Madr[i]) + pp) | (pp << 12) for i in by_level[l] for pp in range(1, l + 1)]
-        if len(ent) > W2:
-            raise ValueError("more than %d L entries on one depth level" % W2)
-        row = np.full(W2, -1, np.int32)
-        row[:len(ent)] = ent
-        irows.append(row)
-    k["k_linv"] = np.stack(irows + [np.full(W2, -1, np.int32)] * PF).astype(np.int32)     # [dmax + PF][W2]
+    # inversion W = I - L^-1 (strictly lower part, same tree sparsity as L), in place, shallow -> deep, Gauss-Jordan by
+    # levels: when the dofs k of a level are processed, every descendant row i does W_ia -= W_ik W_ka for the strict
+    # ancestors a of k.  W_ik still holds L_ik (only deeper levels write it), row k is final, and each target is written
+    # once per level.  The triangular solves then are two independent sparse products (see Wave::ldl_solve).
+    levels = []
+    for l in range(1, dmax):
+        ops = []
+        for kk in by_level[l]:
+            for i in range(kk + 1, int(last_desc[kk]) + 1):
+                mk = int(Madr[i] + ddepth[i] - l)
+                for da in range(l):                                   # ancestor a of k at depth da
+                    ops.append((mk | (int(Madr[kk] + l - da) << 12), int(Madr[i] + ddepth[i] - da)))
+        lv = []
+        for r0 in range(0, len(ops), LANES):
+            row = np.full((LANES, 2), -1, np.int32)
+            blk = ops[r0:r0 + LANES]
+            row[:len(blk)] = blk
+            lv.append((row, 1))
+        levels.append(lv)
+    k["k_linv"], k["k_linv_flag"], k["k_linv_rows"] = pack_levels(levels)
     # ancestor dof ids of every dof, nearest first, 4 per int: [9][NVS * 64]
     if dmax > 36:
         raise ValueError("dof depth above 36")

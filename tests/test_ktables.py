@@ -46,36 +46,49 @@ def test_mulm_table(model_and_state):
     np.testing.assert_allclose(y[:nv], Md @ x, rtol=1e-12, atol=1e-14)
 
 
-def kernel_factor(m, qM):
-    """numpy restatement of Wave::factor: per level, gather rows by target entry (k_factor3), plain read-modify-write on
-    the rows flagged 1, level hand-off on the rows flagged 2; then the row scaling by 1/D."""
-    nv = int(m["nv"])
-    L = qM.copy()
-    tab, flag, R = m["k_factor3"], m["k_factor3_flag"], int(m["k_factor3_rows"])
+PF = 4
+
+
+def run_levels(L, tab, flag, nrows, div):
+    """numpy restatement of Wave::run_levels: blocks of PF rows; all reads of a block (sources and the old target values)
+    are taken before its writes; a level's sources are never written inside the level."""
     acc = np.zeros(LANES)
-    dst = np.full(LANES, -1)
-    written_in_level, read_in_level = set(), set()
-    for r in range(R):
-        e = tab[r]
-        ok = e[:, 0] >= 0
-        a, bq, piv = e[ok, 0] & 4095, e[ok, 0] >> 12, e[ok, 1] >> 12
-        read_in_level.update(a.tolist()); read_in_level.update(bq.tolist()); read_in_level.update(piv.tolist())
-        acc[ok] += L[a] / L[piv] * L[bq]
-        has = e[:, 1] >= 0
-        assert np.all(dst[has] == -1) or np.all(dst[has] == (e[has, 1] & 4095))   # one target per lane within a group
-        dst[has] = e[has, 1] & 4095
-        if flag[r] & 1:
-            t = dst[dst >= 0]
-            assert len(set(t.tolist())) == len(t)                                # plain RMW: no two lanes share a target
-            assert not (set(t.tolist()) & written_in_level)                      # one RMW per target and level
-            written_in_level.update(t.tolist())
-            L[t] -= acc[dst >= 0]
-            acc[:] = 0.0
-            dst[:] = -1
-        if flag[r] & 2:
-            assert not (written_in_level & read_in_level)                        # reads of a level never see its writes
-            written_in_level, read_in_level = set(), set()
-    assert np.all(acc == 0.0) and np.all(tab[R:] == -1)
+    written, read = set(), set()
+    assert nrows % PF == 0 and tab.shape[0] == nrows + PF and np.all(tab[nrows:] == -1)
+    for b0 in range(0, nrows, PF):
+        word = int(flag[b0 // PF])
+        snap = L.copy()                                   # what the block's batched reads see
+        for u in range(PF):
+            e = tab[b0 + u]
+            fl = (word >> (2 * u)) & 3
+            ok = e[:, 0] >= 0
+            a, bq = e[ok, 0] & 4095, e[ok, 0] >> 12
+            read.update(a.tolist()); read.update(bq.tolist())
+            if div:
+                piv = e[ok, 1] >> 12
+                read.update(piv.tolist())
+                acc[ok] += snap[bq] * (snap[a] / snap[piv])
+            else:
+                acc[ok] += snap[bq] * snap[a]
+            if fl & 1:
+                has = e[:, 1] >= 0
+                t = e[has, 1] & 4095
+                assert len(set(t.tolist())) == len(t)     # plain RMW: no two lanes share a target
+                assert not (set(t.tolist()) & written)    # one write per target and level
+                written.update(t.tolist())
+                L[t] = snap[t] - acc[has]
+                acc[:] = 0.0
+            assert not (fl & 2) or u == PF - 1            # levels end at block ends
+            if fl & 2:
+                assert not (written & read)               # reads of a level never see its writes
+                assert np.all(acc == 0.0)
+                written, read = set(), set()
+    return L
+
+
+def kernel_factor(m, qM):
+    """numpy restatement of Wave::factor: gather rows by target entry (k_factor3), then the row scaling by 1/D."""
+    L = run_levels(qM.copy(), m["k_factor3"], m["k_factor3_flag"], int(m["k_factor3_rows"]), True)
     Madr = m["k_dof_i"][:, 4]
     dinv = 1.0 / L[Madr]
     ij = m["k_M_ij"]
@@ -86,28 +99,12 @@ def kernel_factor(m, qM):
 
 
 def kernel_invert(m, L):
-    """numpy restatement of Wave::invert: U = L^-1 in place, one k_linv row per depth level (read phase, then write)."""
-    U = L.copy()
-    rowadr = m["k_M_rowadr"]
-    tab = m["k_linv"]
-    dmax = int(m["k_dof_i"][:, 3].max())
-    for l in range(dmax):
-        e = tab[l][tab[l] >= 0]
-        adr, p = e & 4095, e >> 12
-        val = np.zeros(len(e))
-        for n in range(len(e)):
-            mi = adr[n] - p[n]
-            sm = U[adr[n]]
-            for q in range(1, p[n]):
-                sm += U[mi + q] * U[rowadr[mi + q] + p[n] - q]
-            val[n] = -sm
-        U[adr] = val
-    assert np.all(tab[dmax:] == -1)
-    return U
+    """numpy restatement of Wave::invert: W = I - L^-1 in place (k_linv)."""
+    return run_levels(L.copy(), m["k_linv"], m["k_linv_flag"], int(m["k_linv_rows"]), False)
 
 
-def kernel_solve(m, U, dinv, b):
-    """numpy restatement of Wave::ldl_solve with the explicit inverse: x = U D^-1 U' b (unit diagonal implied).
+def kernel_solve(m, W, dinv, b):
+    """numpy restatement of Wave::ldl_solve with the explicit inverse: x = U D^-1 U' b, U = I - W.
     U' b gathers over the DFS range of descendants (entry of (i, j) at base[i] - depth[j]); U y walks the ancestor chain."""
     nv = int(m["nv"])
     di = m["k_dof_i"]
@@ -116,13 +113,13 @@ def kernel_solve(m, U, dinv, b):
     y = b.copy()
     for j in range(nv):
         for i in range(j + 1, last[j] + 1):
-            y[j] += U[base[i] - depth[j]] * b[i]
+            y[j] -= W[base[i] - depth[j]] * b[i]
     y *= dinv
     x = y.copy()
     for i in range(nv):
         for p in range(1, depth[i] + 1):
             a = (int(chain[(p - 1) >> 2, i]) >> (8 * ((p - 1) & 3))) & 255
-            x[i] += U[Madr[i] + p] * y[a]
+            x[i] -= W[Madr[i] + p] * y[a]
     return x
 
 
@@ -133,6 +130,15 @@ def test_factor_and_solve_tables(model_and_state):
     np.testing.assert_allclose(L, qLD, rtol=1e-9, atol=1e-16)
     np.testing.assert_allclose(dinv, d.get("qLDiagInv"), rtol=1e-9)
     U = kernel_invert(m, L)
+    Ld = np.eye(M.nv)
+    ij = m["k_M_ij"]
+    for e, v in enumerate(ij):
+        if (v & 0xFFFF) != (v >> 16):
+            Ld[v & 0xFFFF, v >> 16] = L[e]
+    Wd = np.eye(M.nv) - np.linalg.inv(Ld)
+    for e, v in enumerate(ij):
+        if (v & 0xFFFF) != (v >> 16):
+            assert abs(U[e] - Wd[v & 0xFFFF, v >> 16]) < 1e-9 * (1 + abs(U[e]))
     Md = dense_from_sparse(m, qM)
     b = np.random.default_rng(2).normal(size=M.nv)
     x = kernel_solve(m, U, dinv, b)
