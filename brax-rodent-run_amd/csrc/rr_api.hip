@@ -49,7 +49,7 @@ static void layout(rr_model* m) {
   k.o_cinert = take(10 * d.nbody);   // composite inertia accumulates in place
   k.o_cdof = take(6 * d.nv); k.o_cvel = take(6 * d.nbody);
   k.o_qM = take(d.nM);
-  k.o_qLD = take(std::max(std::max(d.nM, 12 * d.nbody), 2 * d.nv));   // also cacc | cfrc and the sin/cos scratch
+  k.o_qLD = take(std::max(std::max(d.nM + 3, 12 * d.nbody), 2 * d.nv));   // also cacc | cfrc and the sin/cos scratch
   const int32_t* jadr = (const int32_t*)m->find("con_jadr")->data;
   k.nJ = jadr[d.ncon];
   k.o_vec = take(d.nv); k.o_x = take(d.nv); k.o_y = take(d.nv); k.o_arm = take(2 * d.nv); k.o_warm = take(d.nv); k.o_qact = take(d.nv); k.o_base = take(d.nv);
@@ -104,7 +104,7 @@ extern "C" int rr_model_load(const char* path, rr_model** out) {
   static const char* need[] = {"nq", "nv", "nu", "nbody", "njnt", "ngeom", "nM", "ncon", "nlimit", "nefc", "obs_dim", "k_slots",
                                "k_lvl_adr", "k_lvl_body", "k_child", "k_body_i", "k_body_f", "k_jnt_i", "k_jnt_f", "k_dof_i",
                                "k_dof_f", "k_act_f", "k_M_ij_k", "k_M_rowadr", "k_tri", "k_mulm", "k_solve_fwd", "k_solve_bwd",
-                               "k_solve_bwd_adr", "k_solve_bwd_level", "k_bwd_steps", "k_body_anc", "k_nround", "k_con_chain_bytes", "k_solve2", "k_solve_seq", "k_factor3", "k_factor3_flag", "k_factor3_rows", "k_linv", "k_linv_flag", "k_linv_rows", "k_dof_chain", "k_dof_base", "k_factor2", "k_factor2_first", "k_factor2_rows", "k_con_i", "k_con_f", "k_con_chain", "k_jtf", "k_root_mass", "con_jadr",
+                               "k_solve_bwd_adr", "k_solve_bwd_level", "k_bwd_steps", "k_body_anc", "k_nround", "k_con_chain_bytes", "k_solve2", "k_solve_seq", "k_factor3", "k_factor3_rows", "k_linv", "k_linv_rows", "k_dof_chain", "k_dof_base", "k_factor2", "k_factor2_first", "k_factor2_rows", "k_con_i", "k_con_f", "k_con_chain", "k_jtf", "k_root_mass", "con_jadr",
                                "dof_depth", "body_depth", "opt_timestep", "opt_gravity", "stat_meaninertia"};
   for (const char* nme : need)
     if (!m->find(nme)) { std::string s = std::string("rr_model_load: blob lacks '") + nme + "'"; delete m; return fail(RR_EIO, s); }
@@ -193,6 +193,26 @@ static int upload(rr_batch* b, const char* name, Ptr* dst) {
   return RR_OK;
 }
 
+// Level schedules (k_factor3, k_linv): element indices -> LDS byte addresses of the sparse-matrix array (rr_kernel.h run_levels)
+static int upload_levels(rr_batch* b, const char* name, rr_gi* dst) {
+  const Entry* e = b->m->find(name);
+  const uint32_t base = (uint32_t)b->m->kd.o_qLD * 4u;
+  std::vector<uint32_t> t((const uint32_t*)e->data, (const uint32_t*)e->data + e->count);
+  for (size_t i = 0; i + 1 < t.size(); i += 2) {
+    const uint32_t x = t[i], y = t[i + 1];
+    const uint32_t a = (x & 0xFFFFu) * 4u + base, bq = (x >> 16) * 4u + base, d = (y & 0xFFFFu) * 4u + base, q = ((y >> 16) & 0xFFu) * 4u;
+    if (a > 0xFFFFu || bq > 0xFFFFu || d > 0xFFFFu || q > 0xFFu) return fail(RR_EUNSUPPORTED, "level schedule does not fit the 16-bit LDS address fields");
+    t[i] = a | (bq << 16);
+    t[i + 1] = d | (q << 16) | (y & 0xFF000000u);
+  }
+  void* p = nullptr;
+  HIPCHK(hipMalloc(&p, t.size() * 4));
+  b->dev_allocs.push_back(p);
+  HIPCHK(hipMemcpy(p, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+  *dst = (rr_gi)p;
+  return RR_OK;
+}
+
 typedef void (*kern_t)(const RRDims, const RRTables, const RRIO, const int, const int);
 static kern_t pick_kernel(int nbs, int nvs, int ncs, bool prof = false) {
   if (prof) return (nbs == 2 && nvs == 2 && ncs == 1) ? rr_step_kernel<2, 2, 1, true> : nullptr;
@@ -212,10 +232,11 @@ extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t devi
 #define UP(field, name) if ((rc = upload(b, name, &b->T.field))) { rr_batch_destroy(b); return rc; }
   UP(lvl_adr, "k_lvl_adr") UP(lvl_body, "k_lvl_body") UP(child, "k_child") UP(body_i, "k_body_i") UP(jnt_i, "k_jnt_i")
   UP(dof_i, "k_dof_i") UP(M_ij_k, "k_M_ij_k") UP(M_rowadr, "k_M_rowadr") UP(tri, "k_tri") UP(mulm, "k_mulm")
-  UP(solve_fwd, "k_solve_fwd") UP(solve_bwd, "k_solve_bwd") UP(solve_bwd_adr, "k_solve_bwd_adr") UP(solve_bwd_level, "k_solve_bwd_level") UP(bwd_steps, "k_bwd_steps") UP(body_anc, "k_body_anc") UP(con_chain_packed, "k_con_chain_packed") UP(solve2, "k_solve2") UP(solve_seq, "k_solve_seq") UP(factor3, "k_factor3") UP(factor3_flag, "k_factor3_flag") UP(linv, "k_linv") UP(linv_flag, "k_linv_flag") UP(dof_chain, "k_dof_chain") UP(dof_base, "k_dof_base") UP(factor2, "k_factor2") UP(factor2_first, "k_factor2_first")  UP(con_i, "k_con_i")
+  UP(solve_fwd, "k_solve_fwd") UP(solve_bwd, "k_solve_bwd") UP(solve_bwd_adr, "k_solve_bwd_adr") UP(solve_bwd_level, "k_solve_bwd_level") UP(bwd_steps, "k_bwd_steps") UP(body_anc, "k_body_anc") UP(con_chain_packed, "k_con_chain_packed") UP(solve2, "k_solve2") UP(solve_seq, "k_solve_seq")  UP(dof_chain, "k_dof_chain") UP(dof_base, "k_dof_base") UP(factor2, "k_factor2") UP(factor2_first, "k_factor2_first")  UP(con_i, "k_con_i")
   UP(con_chain, "k_con_chain") UP(jtf, "k_jtf") UP(body_f, "k_body_f") UP(jnt_f, "k_jnt_f") UP(dof_f, "k_dof_f")
   UP(act_f, "k_act_f") UP(con_f, "k_con_f") UP(root_mass, "k_root_mass")
 #undef UP
+  if ((rc = upload_levels(b, "k_factor3", &b->T.factor3)) || (rc = upload_levels(b, "k_linv", &b->T.linv))) { rr_batch_destroy(b); return rc; }
   kern_t kern = pick_kernel(m->NBS, m->NVS, m->NCS);
   if (m->dims.lds_bytes > 64 * 1024) { rr_batch_destroy(b); return fail(RR_EUNSUPPORTED, "rr_batch_create: per-env working set exceeds 160 KiB LDS"); }
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, m->dims.lds_bytes);

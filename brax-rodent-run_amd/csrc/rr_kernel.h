@@ -51,7 +51,7 @@ struct RRDims {
 typedef const int __attribute__((address_space(1)))* rr_gi;
 typedef const float __attribute__((address_space(1)))* rr_gf;
 struct RRTables {
-  rr_gi factor3, factor3_flag, linv, linv_flag, dof_chain, dof_base, lvl_adr, lvl_body, child, body_i, jnt_i, dof_i, M_ij_k, M_rowadr, tri, mulm, solve_fwd, solve_bwd,
+  rr_gi factor3, linv, dof_chain, dof_base, lvl_adr, lvl_body, child, body_i, jnt_i, dof_i, M_ij_k, M_rowadr, tri, mulm, solve_fwd, solve_bwd,
       solve_bwd_adr, solve_bwd_level, bwd_steps, body_anc, con_chain_packed, solve2, solve_seq, factor2, factor2_first, con_i, con_chain, jtf;
   rr_gf body_f, jnt_f, dof_f, act_f, con_f, root_mass;
 };
@@ -693,50 +693,56 @@ struct Wave {
   }
 
   // Executor of the level schedules of the factorisation and the inversion (rodent_amd/ktables.py pack_levels).  A table
-  // row is 64 independent operations (src1 | src2 << 12, dst | piv << 12) on s_qLD; a lane accumulates
-  // src2 * src1 [/ piv] over consecutive rows and, on a row flagged 1, stores dst = dst_old - sum (plain read-modify-write:
-  // within a level every dst belongs to one lane and is written once, and no source of a level is written by that level).
-  // The LDS reads of a block of RR_PF rows -- sources and old target values -- are therefore issued together, one LDS
-  // round trip per block instead of two per row; levels end at block ends (flag 2: one LDS hand-off).  ATOMIC-FREE: an LDS
-  // float atomic costs ~10x a plain read-modify-write on gfx950 and >1000 cycles with every wave of the CU issuing them.
+  // row is 64 independent operations dst -= a * b [/ piv] on the sparse-matrix array s_qLD.  A lane accumulates a * b / piv
+  // over consecutive rows and, on a row flagged 1 (bits 24.. of the second word, the same in every lane), stores
+  // dst = dst_old - sum: a plain read-modify-write -- within a level every dst belongs to one lane and is written once,
+  // and no source of a level is written by that level.  The LDS reads of a block of RR_PF rows -- sources and old target
+  // values -- are therefore issued together, one LDS round trip per block instead of two per row; levels end at block
+  // ends (flag 2: one LDS hand-off).  ATOMIC-FREE: an LDS float atomic costs ~10x a plain read-modify-write on gfx950 and
+  // >1000 cycles with every wave of the CU issuing them.  PREDICATE-FREE: the host turns the table's element indices into
+  // LDS byte addresses at upload, and empty operations address the cells ZERO (0.0), ONE (1.0) and TRASH kept behind the
+  // nM entries, so a row costs 3-4 address extractions, 3-4 ds_reads, the arithmetic and one ds_write.
+  // 1/piv: v_rcp_f32 refined by one Newton step (the row scaling by 1/D after the sweep uses the exact quotient).
   // Rows are prefetched one block ahead (8-byte global loads).
+  typedef float __attribute__((address_space(3)))* rr_lf;
+  static __device__ __forceinline__ float lds_ld(int byte_adr) { return *(rr_lf)(unsigned)byte_adr; }
+  static __device__ __forceinline__ void lds_st(int byte_adr, float v) { *(rr_lf)(unsigned)byte_adr = v; }
   template <bool DIV>
-  __device__ __forceinline__ void run_levels(rr_gi table, rr_gi flags, int nrows) {
+  __device__ __forceinline__ void run_levels(rr_gi table, int nrows) {
     typedef const unsigned long long __attribute__((address_space(1)))* rr_gu64;
     rr_gu64 tab = (rr_gu64)table;
     int2 ring[RR_PF];
 #pragma unroll
     for (int u = 0; u < RR_PF; ++u) { const unsigned long long q_ = tab[u * RR_LANES + lane]; ring[u].x = (int)(unsigned)q_; ring[u].y = (int)(q_ >> 32); }
-    int fw = g_int(flags, 0);
     float acc = 0.0f;
     for (int r0 = 0; r0 < nrows; r0 += RR_PF) {
       int2 e[RR_PF];
-      const int word = fw;
 #pragma unroll
       for (int u = 0; u < RR_PF; ++u) {
         e[u] = ring[u];
         const unsigned long long q_ = tab[(r0 + RR_PF + u) * RR_LANES + lane];
         ring[u].x = (int)(unsigned)q_; ring[u].y = (int)(q_ >> 32);
       }
-      fw = g_int(flags, r0 / RR_PF + 1);
       float va[RR_PF], vb[RR_PF], vp[RR_PF], vo[RR_PF];
 #pragma unroll
-      for (int u = 0; u < RR_PF; ++u) {   // empty operations read entry 0 (the diagonal of dof 0, non-zero) and are masked below
-        const int x0 = e[u].x < 0 ? 0 : e[u].x, y0 = e[u].y < 0 ? 0 : e[u].y;
-        va[u] = s_qLD[x0 & 4095]; vb[u] = s_qLD[x0 >> 12];
-        vp[u] = DIV ? s_qLD[y0 >> 12] : 1.0f;
-        vo[u] = s_qLD[y0 & 4095];
+      for (int u = 0; u < RR_PF; ++u) {
+        const int a4 = e[u].x & 0xFFFF;
+        va[u] = lds_ld(a4); vb[u] = lds_ld((int)((unsigned)e[u].x >> 16));
+        vp[u] = DIV ? lds_ld(a4 - ((e[u].y >> 16) & 0xFF) + 4) : 1.0f;
+        vo[u] = lds_ld(e[u].y & 0xFFFF);
       }
 #pragma unroll
       for (int u = 0; u < RR_PF; ++u) {
-        const float prod = DIV ? vb[u] * (va[u] * (1.0f / vp[u])) : vb[u] * va[u];
-        acc += e[u].x >= 0 ? prod : 0.0f;
-        if ((word >> (2 * u)) & 1) {
-          if (e[u].y >= 0) s_qLD[e[u].y & 4095] = vo[u] - acc;
-          acc = 0.0f;
+        float t = va[u];
+        if (DIV) { float r = __builtin_amdgcn_rcpf(vp[u]); r = r * (2.0f - vp[u] * r); t *= r; }
+        if (DIV) {       // several contribution ranks per target: accumulate, apply on the flagged row
+          acc += vb[u] * t;
+          if ((__builtin_amdgcn_readfirstlane(e[u].y) >> 24) & 1) { lds_st(e[u].y & 0xFFFF, vo[u] - acc); acc = 0.0f; }
+        } else {         // inversion: one contribution per target and level, every row applies
+          lds_st(e[u].y & 0xFFFF, vo[u] - vb[u] * t);
         }
       }
-      if ((word >> (2 * (RR_PF - 1))) & 2) sync();
+      if ((__builtin_amdgcn_readfirstlane(e[RR_PF - 1].y) >> 24) & 2) sync();
     }
   }
 
@@ -747,6 +753,7 @@ struct Wave {
   // rank.  Rows are scaled by 1/D afterwards.
   __device__ __forceinline__ void factor(float damp) {
     for (int e = lane; e < D.nM; e += RR_LANES) s_qLD[e] = s_qM[e];
+    if (lane < 3) s_qLD[D.nM + lane] = lane == 1 ? 1.0f : 0.0f;     // cells ZERO, ONE, TRASH of the level schedules
     sync();
     if (damp != 0.0f) {
 #pragma unroll
@@ -756,7 +763,7 @@ struct Wave {
       }
       sync();
     }
-    run_levels<true>(T.factor3, T.factor3_flag, D.nfac);
+    run_levels<true>(T.factor3, D.nfac);
     sync();
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
@@ -781,7 +788,7 @@ struct Wave {
   // of them per factorisation; with W they become two independent sparse products (ldl_solve).  Gauss-Jordan by depth
   // levels, shallow -> deep (k_linv): when the dofs k of a level are processed every descendant row i does
   // W_ia -= W_ik W_ka over the strict ancestors a of k; W_ik still holds L_ik (only deeper levels write it), row k is final.
-  __device__ __forceinline__ void invert() { run_levels<false>(T.linv, T.linv_flag, D.ninv); }
+  __device__ __forceinline__ void invert() { run_levels<false>(T.linv, D.ninv); }
 
   // x <- (L' D L)^-1 x = U D^-1 U' x  [MuJoCo mj_solveLD] with the explicit inverse factor U = I - W (see invert): no
   // dependent chain, no atomics.  U' x: lane j gathers over its descendants i (a contiguous DFS range), entry (i, j) sits at
@@ -1351,6 +1358,8 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int env = blockIdx.x;
   if (env >= num_envs) return;
+  // the level schedules address LDS by absolute byte address: the dynamic segment must start at 0 (no static LDS here)
+  if ((unsigned)(size_t)(float __attribute__((address_space(3)))*)lds != 0u) __builtin_trap();
   Wave<NBS, NVS, NCS> w(D, T, lds);
   const int lane = threadIdx.x;
   float* dbg = io.dbg ? io.dbg + (size_t)env * D.dbg_floats : nullptr;

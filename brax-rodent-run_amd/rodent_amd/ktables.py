@@ -235,7 +235,7 @@ def build_kernel_tables(m):
                 out.append((Madr[i] + p) | (i << 12) | (int(chain[p]) << 20))
         return out
 
-    if nM >= 4096:
+    if nM >= 4095:
         raise ValueError("nM above the 12-bit address field of the solve tables")
     sol = np.full((max(1, dmax), W2), -1, np.int32)
     for l in range(1, dmax + 1):
@@ -310,30 +310,40 @@ def build_kernel_tables(m):
     k["k_factor2_rows"] = np.int32(len(frows) - PF)
 
     # ---- atomic-free factorisation and inversion schedules.  Both are lists of LEVELS; a level is a list of table rows
-    # of 64 independent operations (src1 | src2 << 12, dst | piv << 12) whose sources are never written inside the level,
-    # so the kernel issues the LDS reads of RR_PF rows (one block) together.  Levels are padded to whole blocks; one flag
-    # word per block carries 2 bits per row: 1 = apply the lane's accumulated sum to dst, 2 = level ends (LDS hand-off).
+    # of 64 independent operations dst -= src_a * src_b [/ piv] on the sparse-matrix array whose sources are never written
+    # inside the level, so the kernel issues the LDS reads of RR_PF rows (one block) together.  Levels are padded to whole
+    # blocks.  Operation = 2 ints:  x = a | b << 16,  y = d | q << 16 | flags << 24  (element indices; piv = a + 1 - q).
+    # The array has three extra cells: ZERO = nM (0.0), ONE = nM + 1 (1.0), TRASH = nM + 2; an empty operation is
+    # a = b = ZERO, q = 0 (piv = ONE), d = TRASH, so the kernel needs no predicates.  flags: 1 = apply the lane's accumulated
+    # sum to d, 2 = level ends (LDS hand-off); they are the same in all 64 lanes of a row.
+    ZERO, TRASH = nM, nM + 2
+
     def pack_levels(levels):
-        rows, flags = [], []
+        rows = []
         for lv in levels:
             if not lv:
                 continue
             lv = list(lv)
             while len(lv) % PF:
-                lv.append((np.full((LANES, 2), -1, np.int32), 0))
-            for b0 in range(0, len(lv), PF):
-                word = 0
-                for u in range(PF):
-                    row, fl = lv[b0 + u]
-                    rows.append(row)
-                    word |= fl << (2 * u)
-                if b0 + PF == len(lv):
-                    word |= 2 << (2 * (PF - 1))
-                flags.append(word)
+                lv.append(([], 0))
+            for t, (ops, fl) in enumerate(lv):
+                if t == len(lv) - 1:
+                    fl |= 2
+                row = np.zeros((LANES, 2), np.int64)
+                row[:, 0] = ZERO | (ZERO << 16)
+                row[:, 1] = TRASH | (fl << 24)
+                for ln, (a_, b_, d_, q_) in enumerate(ops):
+                    if a_ is None:                                  # no contribution on this rank; target kept
+                        row[ln] = (ZERO | (ZERO << 16), d_ | (fl << 24))
+                    else:
+                        row[ln] = (a_ | (b_ << 16), d_ | (q_ << 16) | (fl << 24))
+                rows.append(row)
         nrows = len(rows)
-        rows += [np.full((LANES, 2), -1, np.int32)] * PF          # slack block the ring may prefetch
-        flags += [0]
-        return np.stack(rows).astype(np.int32), np.asarray(flags, np.int32), np.int32(nrows)
+        empty = np.zeros((LANES, 2), np.int64)
+        empty[:, 0] = ZERO | (ZERO << 16)
+        empty[:, 1] = TRASH
+        rows += [empty] * PF                                      # slack block the ring may prefetch
+        return np.stack(rows).astype(np.int32), np.int32(nrows)
 
     # factorisation [MuJoCo mj_factorM], deep -> shallow: the rank-1 updates of a level are grouped by TARGET entry.  A lane
     # owns one target per group of 64 targets and accumulates its contributions L_kp L_kq / D_k over the dofs k of the level
@@ -346,19 +356,16 @@ def build_kernel_tables(m):
             for q in range(1, l + 1):
                 for p in range(1, q + 1):
                     dst = int(Madr[int(chain[p])] + (q - p))
-                    tgt.setdefault(dst, []).append((int(Madr[kk] + p) | (int(Madr[kk] + q) << 12), dst | (int(Madr[kk]) << 12)))
+                    tgt.setdefault(dst, []).append((int(Madr[kk] + p), int(Madr[kk] + q), dst, p + 1))
         order = sorted(tgt, key=lambda d_: (-len(tgt[d_]), d_))          # equal multiplicities share a group
         lv = []
         for g0 in range(0, len(order), LANES):
             grp = order[g0:g0 + LANES]
             mult = max(len(tgt[d_]) for d_ in grp)
             for t in range(mult):
-                row = np.full((LANES, 2), -1, np.int32)
-                for ln, d_ in enumerate(grp):
-                    row[ln] = tgt[d_][t] if t < len(tgt[d_]) else (-1, d_)   # no contribution on this rank; target kept
-                lv.append((row, 1 if t == mult - 1 else 0))
+                lv.append(([tgt[d_][t] if t < len(tgt[d_]) else (None, None, d_, 0) for d_ in grp], 1 if t == mult - 1 else 0))
         levels.append(lv)
-    k["k_factor3"], k["k_factor3_flag"], k["k_factor3_rows"] = pack_levels(levels)
+    k["k_factor3"], k["k_factor3_rows"] = pack_levels(levels)
 
     # inversion W = I - L^-1 (strictly lower part, same tree sparsity as L), in place, shallow -> deep, Gauss-Jordan by
     # levels: when the dofs k of a level are processed, every descendant row i does W_ia -= W_ik W_ka for the strict
@@ -371,15 +378,9 @@ def build_kernel_tables(m):
             for i in range(kk + 1, int(last_desc[kk]) + 1):
                 mk = int(Madr[i] + ddepth[i] - l)
                 for da in range(l):                                   # ancestor a of k at depth da
-                    ops.append((mk | (int(Madr[kk] + l - da) << 12), int(Madr[i] + ddepth[i] - da)))
-        lv = []
-        for r0 in range(0, len(ops), LANES):
-            row = np.full((LANES, 2), -1, np.int32)
-            blk = ops[r0:r0 + LANES]
-            row[:len(blk)] = blk
-            lv.append((row, 1))
-        levels.append(lv)
-    k["k_linv"], k["k_linv_flag"], k["k_linv_rows"] = pack_levels(levels)
+                    ops.append((mk, int(Madr[kk] + l - da), int(Madr[i] + ddepth[i] - da), 0))
+        levels.append([(ops[r0:r0 + LANES], 1) for r0 in range(0, len(ops), LANES)])
+    k["k_linv"], k["k_linv_rows"] = pack_levels(levels)
     # ancestor dof ids of every dof, nearest first, 4 per int: [9][NVS * 64]
     if dmax > 36:
         raise ValueError("dof depth above 36")

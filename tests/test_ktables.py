@@ -49,34 +49,42 @@ def test_mulm_table(model_and_state):
 PF = 4
 
 
-def run_levels(L, tab, flag, nrows, div):
+def run_levels(L, tab, nrows, div):
     """numpy restatement of Wave::run_levels: blocks of PF rows; all reads of a block (sources and the old target values)
-    are taken before its writes; a level's sources are never written inside the level."""
+    are taken before its writes; a level's sources are never written inside the level.  L carries the three extra cells
+    ZERO, ONE, TRASH behind its nM entries."""
+    nM = len(L) - 3
+    assert L[nM] == 0.0 and L[nM + 1] == 1.0
     acc = np.zeros(LANES)
     written, read = set(), set()
-    assert nrows % PF == 0 and tab.shape[0] == nrows + PF and np.all(tab[nrows:] == -1)
+    assert nrows % PF == 0 and tab.shape[0] == nrows + PF
+    assert np.all(tab[nrows:, :, 0] == (nM | nM << 16)) and np.all(tab[nrows:, :, 1] == nM + 2)
     for b0 in range(0, nrows, PF):
-        word = int(flag[b0 // PF])
         snap = L.copy()                                   # what the block's batched reads see
         for u in range(PF):
             e = tab[b0 + u]
-            fl = (word >> (2 * u)) & 3
-            ok = e[:, 0] >= 0
-            a, bq = e[ok, 0] & 4095, e[ok, 0] >> 12
-            read.update(a.tolist()); read.update(bq.tolist())
+            fl = e[0, 1] >> 24
+            assert np.all((e[:, 1] >> 24) == fl) and 0 <= fl < 4
+            a, bq, dst, q = e[:, 0] & 0xFFFF, (e[:, 0] >> 16) & 0xFFFF, e[:, 1] & 0xFFFF, (e[:, 1] >> 16) & 0xFF
+            real = a != nM
+            assert np.all(bq[~real] == nM) and np.all(q[~real] == 0) and np.all(dst[real] < nM)
+            read.update(a[real].tolist()); read.update(bq[real].tolist())
             if div:
-                piv = e[ok, 1] >> 12
-                read.update(piv.tolist())
-                acc[ok] += snap[bq] * (snap[a] / snap[piv])
+                piv = a + 1 - q
+                assert np.all(piv[~real] == nM + 1) and np.all(piv[real] < nM)
+                read.update(piv[real].tolist())
+                acc += snap[bq] * (snap[a] / snap[piv])
             else:
-                acc[ok] += snap[bq] * snap[a]
+                assert np.all(q == 0)
+                acc += snap[bq] * snap[a]
             if fl & 1:
-                has = e[:, 1] >= 0
-                t = e[has, 1] & 4095
+                has = dst < nM
+                t = dst[has]
+                assert np.all(dst[~has] == nM + 2) and np.all(acc[~has] == 0.0)
                 assert len(set(t.tolist())) == len(t)     # plain RMW: no two lanes share a target
                 assert not (set(t.tolist()) & written)    # one write per target and level
                 written.update(t.tolist())
-                L[t] = snap[t] - acc[has]
+                L[dst] = snap[dst] - acc                  # lanes without a target rewrite TRASH with itself
                 acc[:] = 0.0
             assert not (fl & 2) or u == PF - 1            # levels end at block ends
             if fl & 2:
@@ -88,7 +96,7 @@ def run_levels(L, tab, flag, nrows, div):
 
 def kernel_factor(m, qM):
     """numpy restatement of Wave::factor: gather rows by target entry (k_factor3), then the row scaling by 1/D."""
-    L = run_levels(qM.copy(), m["k_factor3"], m["k_factor3_flag"], int(m["k_factor3_rows"]), True)
+    L = run_levels(np.concatenate([qM, [0.0, 1.0, 0.0]]), m["k_factor3"], int(m["k_factor3_rows"]), True)[:len(qM)]
     Madr = m["k_dof_i"][:, 4]
     dinv = 1.0 / L[Madr]
     ij = m["k_M_ij"]
@@ -100,7 +108,7 @@ def kernel_factor(m, qM):
 
 def kernel_invert(m, L):
     """numpy restatement of Wave::invert: W = I - L^-1 in place (k_linv)."""
-    return run_levels(L.copy(), m["k_linv"], m["k_linv_flag"], int(m["k_linv_rows"]), False)
+    return run_levels(np.concatenate([L, [0.0, 1.0, 0.0]]), m["k_linv"], int(m["k_linv_rows"]), False)[:len(L)]
 
 
 def kernel_solve(m, W, dinv, b):
