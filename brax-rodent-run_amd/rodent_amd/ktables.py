@@ -338,11 +338,13 @@ def build_kernel_tables(m):
                     else:
                         row[ln] = (a_ | (b_ << 16), d_ | (q_ << 16) | (fl << 24))
                 rows.append(row)
-        nrows = len(rows)
         empty = np.zeros((LANES, 2), np.int64)
         empty[:, 0] = ZERO | (ZERO << 16)
         empty[:, 1] = TRASH
-        rows += [empty] * PF                                      # slack block the ring may prefetch
+        while len(rows) % (2 * PF):                               # the kernel consumes two blocks per loop trip
+            rows.append(empty)
+        nrows = len(rows)
+        rows += [empty] * (2 * PF)                                # slack blocks the ring may prefetch
         return np.stack(rows).astype(np.int32), np.int32(nrows)
 
     # factorisation [MuJoCo mj_factorM], deep -> shallow: the rank-1 updates of a level are grouped by TARGET entry.  A lane

@@ -57,7 +57,7 @@ def run_levels(L, tab, nrows, div):
     assert L[nM] == 0.0 and L[nM + 1] == 1.0
     acc = np.zeros(LANES)
     written, read = set(), set()
-    assert nrows % PF == 0 and tab.shape[0] == nrows + PF
+    assert nrows % (2 * PF) == 0 and tab.shape[0] == nrows + 2 * PF
     assert np.all(tab[nrows:, :, 0] == (nM | nM << 16)) and np.all(tab[nrows:, :, 1] == nM + 2)
     for b0 in range(0, nrows, PF):
         snap = L.copy()                                   # what the block's batched reads see
