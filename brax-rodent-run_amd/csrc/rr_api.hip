@@ -104,7 +104,7 @@ extern "C" int rr_model_load(const char* path, rr_model** out) {
   static const char* need[] = {"nq", "nv", "nu", "nbody", "njnt", "ngeom", "nM", "ncon", "nlimit", "nefc", "obs_dim", "k_slots",
                                "k_lvl_adr", "k_lvl_body", "k_child", "k_body_i", "k_body_f", "k_jnt_i", "k_jnt_f", "k_dof_i",
                                "k_dof_f", "k_act_f", "k_M_ij_k", "k_M_rowadr", "k_tri", "k_mulm", "k_solve_fwd", "k_solve_bwd",
-                               "k_solve_bwd_adr", "k_solve_bwd_level", "k_bwd_steps", "k_body_anc", "k_nround", "k_con_chain_bytes", "k_solve2", "k_solve_seq", "k_factor3", "k_factor3_rows", "k_linv", "k_linv_rows", "k_dof_chain", "k_dof_base", "k_factor2", "k_factor2_first", "k_factor2_rows", "k_con_i", "k_con_f", "k_con_chain", "k_jtf", "k_root_mass", "con_jadr",
+                               "k_solve_bwd_adr", "k_solve_bwd_level", "k_bwd_steps", "k_body_anc", "k_nround", "k_con_chain_bytes", "k_solve2", "k_solve_seq", "k_factor3", "k_factor3_rows", "k_linv", "k_coljob", "k_rowjob", "k_rowjob_chain", "k_jobown", "k_solve_lmax", "k_linv_rows", "k_dof_chain", "k_dof_base", "k_factor2", "k_factor2_first", "k_factor2_rows", "k_con_i", "k_con_f", "k_con_chain", "k_jtf", "k_root_mass", "con_jadr",
                                "dof_depth", "body_depth", "opt_timestep", "opt_gravity", "stat_meaninertia"};
   for (const char* nme : need)
     if (!m->find(nme)) { std::string s = std::string("rr_model_load: blob lacks '") + nme + "'"; delete m; return fail(RR_EIO, s); }
@@ -232,7 +232,7 @@ extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t devi
 #define UP(field, name) if ((rc = upload(b, name, &b->T.field))) { rr_batch_destroy(b); return rc; }
   UP(lvl_adr, "k_lvl_adr") UP(lvl_body, "k_lvl_body") UP(child, "k_child") UP(body_i, "k_body_i") UP(jnt_i, "k_jnt_i")
   UP(dof_i, "k_dof_i") UP(M_ij_k, "k_M_ij_k") UP(M_rowadr, "k_M_rowadr") UP(tri, "k_tri") UP(mulm, "k_mulm")
-  UP(solve_fwd, "k_solve_fwd") UP(solve_bwd, "k_solve_bwd") UP(solve_bwd_adr, "k_solve_bwd_adr") UP(solve_bwd_level, "k_solve_bwd_level") UP(bwd_steps, "k_bwd_steps") UP(body_anc, "k_body_anc") UP(con_chain_packed, "k_con_chain_packed") UP(solve2, "k_solve2") UP(solve_seq, "k_solve_seq")  UP(dof_chain, "k_dof_chain") UP(dof_base, "k_dof_base") UP(factor2, "k_factor2") UP(factor2_first, "k_factor2_first")  UP(con_i, "k_con_i")
+  UP(solve_fwd, "k_solve_fwd") UP(solve_bwd, "k_solve_bwd") UP(solve_bwd_adr, "k_solve_bwd_adr") UP(solve_bwd_level, "k_solve_bwd_level") UP(bwd_steps, "k_bwd_steps") UP(body_anc, "k_body_anc") UP(con_chain_packed, "k_con_chain_packed") UP(solve2, "k_solve2") UP(solve_seq, "k_solve_seq")  UP(coljob, "k_coljob") UP(rowjob, "k_rowjob") UP(rowjob_chain, "k_rowjob_chain") UP(jobown, "k_jobown") UP(dof_chain, "k_dof_chain") UP(dof_base, "k_dof_base") UP(factor2, "k_factor2") UP(factor2_first, "k_factor2_first")  UP(con_i, "k_con_i")
   UP(con_chain, "k_con_chain") UP(jtf, "k_jtf") UP(body_f, "k_body_f") UP(jnt_f, "k_jnt_f") UP(dof_f, "k_dof_f")
   UP(act_f, "k_act_f") UP(con_f, "k_con_f") UP(root_mass, "k_root_mass")
 #undef UP

@@ -51,7 +51,7 @@ struct RRDims {
 typedef const int __attribute__((address_space(1)))* rr_gi;
 typedef const float __attribute__((address_space(1)))* rr_gf;
 struct RRTables {
-  rr_gi factor3, linv, dof_chain, dof_base, lvl_adr, lvl_body, child, body_i, jnt_i, dof_i, M_ij_k, M_rowadr, tri, mulm, solve_fwd, solve_bwd,
+  rr_gi factor3, linv, coljob, rowjob, rowjob_chain, jobown, dof_chain, dof_base, lvl_adr, lvl_body, child, body_i, jnt_i, dof_i, M_ij_k, M_rowadr, tri, mulm, solve_fwd, solve_bwd,
       solve_bwd_adr, solve_bwd_level, bwd_steps, body_anc, con_chain_packed, solve2, solve_seq, factor2, factor2_first, con_i, con_chain, jtf;
   rr_gf body_f, jnt_f, dof_f, act_f, con_f, root_mass;
 };
@@ -705,8 +705,8 @@ struct Wave {
   // 1/piv: v_rcp_f32 refined by one Newton step (the row scaling by 1/D after the sweep uses the exact quotient).
   // Rows are prefetched one block ahead (8-byte global loads).
   typedef float __attribute__((address_space(3)))* rr_lf;
-  static __device__ __forceinline__ float lds_ld(int byte_adr) { return *(rr_lf)(unsigned)byte_adr; }
-  static __device__ __forceinline__ void lds_st(int byte_adr, float v) { *(rr_lf)(unsigned)byte_adr = v; }
+  static __device__ __forceinline__ float lds_ld(int byte_adr) { return *(rr_lf)(size_t)(unsigned)byte_adr; }
+  static __device__ __forceinline__ void lds_st(int byte_adr, float v) { *(rr_lf)(size_t)(unsigned)byte_adr = v; }
   template <bool DIV>
   __device__ __forceinline__ void run_levels(rr_gi table, int nrows) {
     typedef const unsigned long long __attribute__((address_space(1)))* rr_gu64;
@@ -794,55 +794,74 @@ struct Wave {
   __device__ __forceinline__ void invert() { run_levels<false>(T.linv, D.ninv); }
 
   // x <- (L' D L)^-1 x = U D^-1 U' x  [MuJoCo mj_solveLD] with the explicit inverse factor U = I - W (see invert): no
-  // dependent chain, no atomics.  U' x: lane j gathers over its descendants i (a contiguous DFS range), entry (i, j) sits at
-  // base[i] - depth[j];  U y: lane i walks its ancestor chain (ids packed 4 per register, loaded per call), entry (i, p)
-  // at Madr[i] + p.  Lane d owns x_d.
+  // dependent chain, no atomics.  U' b sums column j over its descendants i (a contiguous DFS range, entry (i, j) at
+  // base[i] - depth[j]); U y sums row i over its ancestors (entry (i, p) at Madr[i] + p).  Both products are nM - nv
+  // multiply-adds but the longest column / row is ~nv / ~depth long, so each is cut into balanced pieces of at most
+  // D.lmax (<= 16) entries, one piece per lane and job slot (k_coljob / k_rowjob); the piece sums go through the (dead)
+  // pose cells s_buf and the owner lane of the column / row adds up its pieces.  Lane d owns x_d.
+  static constexpr int NJS = NVS >= 3 ? NVS + 1 : NVS;      // job slots per lane (ktables: nslot)
   __device__ __forceinline__ void ldl_solve(float* x) {
-    constexpr int W = NVS * RR_LANES;
-    int ch[NVS][9];
+    constexpr int WJ = NJS * RR_LANES;
+    int cj[NJS], rj[NJS], rch[NJS][4], own[NVS];
     {
       const int ol = opaque(lane);
 #pragma unroll
-      for (int s = 0; s < NVS; ++s)
+      for (int s = 0; s < NJS; ++s) {
+        cj[s] = g_int(T.coljob, s * RR_LANES + ol);
+        rj[s] = g_int(T.rowjob, s * RR_LANES + ol);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) ch[s][k] = g_int(T.dof_chain, k * W + s * RR_LANES + ol);
+        for (int k = 0; k < 4; ++k) rch[s][k] = g_int(T.rowjob_chain, k * WJ + s * RR_LANES + ol);
+      }
+#pragma unroll
+      for (int s = 0; s < NVS; ++s) own[s] = ol + RR_LANES * s < D.nv ? g_int(T.jobown, ol + RR_LANES * s) : 0;
     }
 #pragma unroll
     for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; if (d < D.nv) s_x[d] = x[s]; }
     sync();
+#pragma unroll
+    for (int s = 0; s < NJS; ++s) {
+      const int i0 = (cj[s] >> 8) & 255, n = (cj[s] >> 16) & 255, dj = (int)((unsigned)cj[s] >> 24);
+      float acc = 0.0f;
+#pragma unroll 4
+      for (int t = 0; t < n; ++t) acc += s_qLD[s_base[i0 + t] - dj] * s_x[i0 + t];
+      s_buf[s * RR_LANES + lane] = acc;
+    }
+    sync();
     float y[NVS];
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
-      const int j = lane + RR_LANES * s;
-      float acc = x[s];
-      if (j < D.nv) {
-        const int dj = opaque(dofc0[s]) & 255, last = opaque(dofc1[s]) >> 16;
-#pragma unroll 4
-        for (int i = j + 1; i <= last; ++i) acc -= s_qLD[s_base[i] - dj] * s_x[i];
-      }
-      y[s] = acc * dinv[s];
+      const int t0 = own[s] & 255, c = (own[s] >> 8) & 255;
+      float sum = 0.0f;
+      for (int r = 0; r < c; ++r) sum += s_buf[t0 + r];
+      y[s] = (x[s] - sum) * dinv[s];
     }
     sync();
 #pragma unroll
     for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; if (d < D.nv) s_x[d] = y[s]; }
     sync();
 #pragma unroll
-    for (int s = 0; s < NVS; ++s) {
-      const int d = lane + RR_LANES * s;
-      float acc = y[s];
-      const int depth = d < D.nv ? (opaque(dofc0[s]) & 255) : 0, madr = opaque(dofc1[s]) & 0xFFFF;
+    for (int s = 0; s < NJS; ++s) {
+      const int adr0 = rj[s] & 4095, n = rj[s] >> 12;
+      float acc = 0.0f;
 #pragma unroll
-      for (int p0 = 0; p0 < 36; p0 += 4) {
-        if (__any(p0 < depth)) {
+      for (int t0 = 0; t0 < 16; t0 += 4) {
+        if (__any(t0 < n)) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int p = p0 + u + 1;
-            if (p <= depth) acc -= s_qLD[madr + p] * s_x[(ch[s][p0 >> 2] >> (8 * u)) & 255];
-          }
+          for (int u = 0; u < 4; ++u)
+            if (t0 + u < n) acc += s_qLD[adr0 + t0 + u] * s_x[(rch[s][t0 >> 2] >> (8 * u)) & 255];
         }
       }
-      x[s] = acc;
+      s_buf[s * RR_LANES + lane] = acc;
     }
+    sync();
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) {
+      const int t0 = (own[s] >> 16) & 255, c = (int)((unsigned)own[s] >> 24);
+      float sum = 0.0f;
+      for (int r = 0; r < c; ++r) sum += s_buf[t0 + r];
+      x[s] = y[s] - sum;
+    }
+    sync();     // s_buf is reused by the next solve
   }
 
   // y = M * s_vec (s_vec must be visible).  Entry-parallel: lane owns matrix entries e = lane + 64 it (row/col ids

@@ -394,6 +394,53 @@ def build_kernel_tables(m):
     k["k_dof_chain"] = (dch & 0xFFFFFFFF).astype(np.uint32).view(np.int32).reshape(9, Wd)
     k["k_dof_base"] = (Madr[:nv] + ddepth[:nv]).astype(np.int32)   # entry (i, j) of a descendant i sits at base[i] - depth[j]
 
+    # ---- balanced jobs of the two sparse products of the solve (Wave::ldl_solve).  Column product (U' b): column j sums
+    # over its descendants i = j+1 .. last_desc[j]; row product (U y): row i sums over its ancestors p = 1 .. depth[i].  Both
+    # total nM - nv multiply-adds but the longest column / row is ~nv / ~dmax long, so each is cut into pieces of at most
+    # LMAX entries, one piece per lane-slot (NVS * 64 of them); the owner of a column / row adds up its pieces' partial sums.
+    nslot = (NVS + 1 if NVS >= 3 else NVS) * LANES          # Wave::NJS job slots per lane
+    lmax = 1
+    while True:
+        ncj = sum(-(-int(last_desc[j] - j) // lmax) for j in range(nv))
+        nrj = sum(-(-int(ddepth[i]) // lmax) for i in range(nv))
+        if ncj <= nslot and nrj <= nslot:
+            break
+        lmax += 1
+    if lmax > 16:
+        raise ValueError("solve jobs longer than 16 entries")
+    coljob = np.zeros(nslot, np.int64)          # j | i0 << 8 | n << 16 | depth[j] << 24   (n = 0: no job)
+    rowjob = np.zeros(nslot, np.int64)          # Madr[i] + p0 | n << 12
+    rowch = np.zeros((4, nslot), np.int64)      # ancestor dof ids of the piece, 4 per int
+    own = np.zeros(nv, np.int64)                # first column job | count << 8 | first row job << 16 | count << 24
+    t = 0
+    for j in range(nv):
+        n = int(last_desc[j] - j)
+        c = -(-n // lmax)
+        own[j] |= t | (c << 8)
+        for r in range(c):
+            i0 = j + 1 + r * n // c
+            i1 = j + 1 + (r + 1) * n // c
+            coljob[t] = j | (i0 << 8) | ((i1 - i0) << 16) | (int(ddepth[j]) << 24)
+            t += 1
+    t = 0
+    for i in range(nv):
+        n = int(ddepth[i])
+        c = -(-n // lmax)
+        own[i] |= (t << 16) | (c << 24)
+        chain = anc[anc_adr[i]:anc_adr[i + 1]][::-1]     # self, parent, ..., root
+        for r in range(c):
+            p0 = 1 + r * n // c
+            p1 = 1 + (r + 1) * n // c
+            rowjob[t] = int(Madr[i] + p0) | ((p1 - p0) << 12)
+            for u, pp in enumerate(range(p0, p1)):
+                rowch[u >> 2, t] |= int(chain[pp]) << (8 * (u & 3))
+            t += 1
+    k["k_solve_lmax"] = np.int32(lmax)
+    k["k_coljob"] = (coljob & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+    k["k_rowjob"] = rowjob.astype(np.int32)
+    k["k_rowjob_chain"] = (rowch & 0xFFFFFFFF).astype(np.uint32).view(np.int32).reshape(4, nslot)
+    k["k_jobown"] = (own & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+
     # ---- contacts
     WC = NCS * LANES
     g2 = m["con_geom2"]

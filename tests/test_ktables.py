@@ -112,23 +112,26 @@ def kernel_invert(m, L):
 
 
 def kernel_solve(m, W, dinv, b):
-    """numpy restatement of Wave::ldl_solve with the explicit inverse: x = U D^-1 U' b, U = I - W.
-    U' b gathers over the DFS range of descendants (entry of (i, j) at base[i] - depth[j]); U y walks the ancestor chain."""
+    """numpy restatement of Wave::ldl_solve with the explicit inverse: x = U D^-1 U' b, U = I - W, both products cut into
+    balanced per-lane-slot jobs (k_coljob / k_rowjob) whose partial sums the owner of the column / row adds up."""
     nv = int(m["nv"])
-    di = m["k_dof_i"]
-    depth, Madr, last = di[:, 3], di[:, 4], di[:, 10]
-    base, chain = m["k_dof_base"], m["k_dof_chain"]
-    y = b.copy()
-    for j in range(nv):
-        for i in range(j + 1, last[j] + 1):
-            y[j] -= W[base[i] - depth[j]] * b[i]
-    y *= dinv
-    x = y.copy()
-    for i in range(nv):
-        for p in range(1, depth[i] + 1):
-            a = (int(chain[(p - 1) >> 2, i]) >> (8 * ((p - 1) & 3))) & 255
-            x[i] -= W[Madr[i] + p] * y[a]
-    return x
+    base = m["k_dof_base"]
+    cj, rj, rch, own = m["k_coljob"].view(np.uint32), m["k_rowjob"], m["k_rowjob_chain"].view(np.uint32), m["k_jobown"].view(np.uint32)
+    lmax = int(m["k_solve_lmax"])
+    part = np.zeros(len(cj))
+    for t, e in enumerate(cj):
+        j, i0, n, dj = int(e & 255), int((e >> 8) & 255), int((e >> 16) & 255), int(e >> 24)
+        assert n <= lmax
+        for i in range(i0, i0 + n):
+            part[t] += W[base[i] - dj] * b[i]
+    y = np.array([(b[j] - part[int(own[j] & 255):int(own[j] & 255) + int((own[j] >> 8) & 255)].sum()) * dinv[j] for j in range(nv)])
+    part = np.zeros(len(rj))
+    for t, e in enumerate(rj):
+        adr0, n = int(e & 4095), int(e >> 12)
+        assert n <= lmax
+        for u in range(n):
+            part[t] += W[adr0 + u] * y[(int(rch[u >> 2, t]) >> (8 * (u & 3))) & 255]
+    return np.array([y[i] - part[int((own[i] >> 16) & 255):int((own[i] >> 16) & 255) + int(own[i] >> 24)].sum() for i in range(nv)])
 
 
 def test_factor_and_solve_tables(model_and_state):
