@@ -800,21 +800,23 @@ struct Wave {
   // D.lmax (<= 16) entries, one piece per lane and job slot (k_coljob / k_rowjob); the piece sums go through the (dead)
   // pose cells s_buf and the owner lane of the column / row adds up its pieces.  Lane d owns x_d.
   static constexpr int NJS = NVS >= 3 ? NVS + 1 : NVS;      // job slots per lane (ktables: nslot)
-  __device__ __forceinline__ void ldl_solve(float* x) {
+  // this lane's jobs, reloaded per call from the L2-resident tables (held across the solver they would be spilled)
+  __device__ __forceinline__ void load_jobs(int* cj, int* rj, int (*rch)[4], int* own) {
     constexpr int WJ = NJS * RR_LANES;
-    int cj[NJS], rj[NJS], rch[NJS][4], own[NVS];
-    {
-      const int ol = opaque(lane);
+    const int ol = opaque(lane);
 #pragma unroll
-      for (int s = 0; s < NJS; ++s) {
-        cj[s] = g_int(T.coljob, s * RR_LANES + ol);
-        rj[s] = g_int(T.rowjob, s * RR_LANES + ol);
+    for (int s = 0; s < NJS; ++s) {
+      cj[s] = g_int(T.coljob, s * RR_LANES + ol);
+      rj[s] = g_int(T.rowjob, s * RR_LANES + ol);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) rch[s][k] = g_int(T.rowjob_chain, k * WJ + s * RR_LANES + ol);
-      }
-#pragma unroll
-      for (int s = 0; s < NVS; ++s) own[s] = ol + RR_LANES * s < D.nv ? g_int(T.jobown, ol + RR_LANES * s) : 0;
+      for (int k = 0; k < 4; ++k) rch[s][k] = g_int(T.rowjob_chain, k * WJ + s * RR_LANES + ol);
     }
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) own[s] = ol + RR_LANES * s < D.nv ? g_int(T.jobown, ol + RR_LANES * s) : 0;
+  }
+  __device__ __forceinline__ void ldl_solve(float* x) {
+    int cj[NJS], rj[NJS], rch[NJS][4], own[NVS];
+    load_jobs(cj, rj, rch, own);
 #pragma unroll
     for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; if (d < D.nv) s_x[d] = x[s]; }
     sync();
@@ -864,25 +866,45 @@ struct Wave {
     sync();     // s_buf is reused by the next solve
   }
 
-  // y = M * s_vec (s_vec must be visible).  Entry-parallel: lane owns matrix entries e = lane + 64 it (row/col ids
-  // in registers) and adds M_ij x_j to y_i and M_ij x_i to y_j with LDS float atomics: perfectly balanced, no tables.
+  // y = M * s_vec (s_vec must be visible).  Row i of the symmetric product is its ancestor part (entries of row i) plus
+  // its descendant part (entries (k, i) of the rows below): the two sparse products of ldl_solve on the same vector, with
+  // the same balanced jobs (k_coljob / k_rowjob), on s_qM.  No atomics.
   __device__ __forceinline__ void mul_m(float* y) {
+    constexpr int WJ = NJS * RR_LANES;
+    int cj[NJS], rj[NJS], rch[NJS][4], own[NVS];
+    load_jobs(cj, rj, rch, own);
 #pragma unroll
-    for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; if (d < D.nv) s_y[d] = 0.0f; }
-    sync();
+    for (int s = 0; s < NJS; ++s) {
+      const int i0 = (cj[s] >> 8) & 255, n = (cj[s] >> 16) & 255, dj = (int)((unsigned)cj[s] >> 24);
+      float acc = 0.0f;
+#pragma unroll 4
+      for (int t = 0; t < n; ++t) acc += s_qM[s_base[i0 + t] - dj] * s_vec[i0 + t];
+      s_buf[s * RR_LANES + lane] = acc;
+      const int adr0 = rj[s] & 4095, nr = rj[s] >> 12;
+      acc = 0.0f;
 #pragma unroll
-    for (int it = 0; it < NME; ++it) {
-      const int ij = opaque(ment[it]);
-      if (ij >= 0) {
-        const int i = ij & 255, j = ij >> 8;
-        const float mij = s_qM[lane + RR_LANES * it];
-        atomicAdd(s_y + i, mij * s_vec[j]);
-        if (i != j) atomicAdd(s_y + j, mij * s_vec[i]);
+      for (int t0 = 0; t0 < 16; t0 += 4) {
+        if (__any(t0 < nr)) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (t0 + u < nr) acc += s_qM[adr0 + t0 + u] * s_vec[(rch[s][t0 >> 2] >> (8 * u)) & 255];
+        }
       }
+      s_buf[WJ + s * RR_LANES + lane] = acc;
     }
     sync();
 #pragma unroll
-    for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; y[s] = d < D.nv ? s_y[d] : 0.0f; }
+    for (int s = 0; s < NVS; ++s) {
+      const int d = lane + RR_LANES * s;
+      float sum = 0.0f;
+      if (d < D.nv) {
+        sum = s_qM[opaque(dofc1[s]) & 0xFFFF] * s_vec[d];
+        const int t0 = own[s] & 255, c = (own[s] >> 8) & 255, r0 = (own[s] >> 16) & 255, cr = (int)((unsigned)own[s] >> 24);
+        for (int r = 0; r < c; ++r) sum += s_buf[t0 + r];
+        for (int r = 0; r < cr; ++r) sum += s_buf[WJ + r0 + r];
+      }
+      y[s] = sum;
+    }
     sync();
   }
 
@@ -1084,11 +1106,22 @@ struct Wave {
   // constraint state at the current Jaref: forces, qfrc_constraint, cost  [UP mjx solver._update_constraint]
   __device__ __forceinline__ void update_constraint() {
     float part[2] = {0.0f, 0.0f};  // [0] = sum D*Jaref^2 over active rows, [1] = gauss dot
+    // J' f without a Jacobian and without atomics: a contact pushes with the spatial force (tau about the tree COM, F)
+    // on every dof of its body's ancestor chain, qfrc_d += cdof_d . (tau, F).  The wave walks the contacts that carry
+    // force (ballot), broadcasts each one's force and leaf dof (readlane), and every dof lane tests "am I on that chain"
+    // by the DFS interval  d <= leaf <= last_desc(d).
+    float qc[NVS], cd[NVS][6];
 #pragma unroll
-    for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; if (d < D.nv) s_y[d] = 0.0f; }
-    sync();
+    for (int s = 0; s < NVS; ++s) {
+      const int d = lane + RR_LANES * s;
+      qc[s] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) cd[s][k] = d < D.nv ? s_cdof[6 * d + k] : 0.0f;
+    }
 #pragma unroll
     for (int cs = 0; cs < NCS; ++cs) {
+      float W[6] = {0, 0, 0, 0, 0, 0};
+      bool has = false;
       if (con_act[cs]) {
         float f[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -1098,42 +1131,42 @@ struct Wave {
         }
         const float mu = con_mu[cs];
         const float fn = f[0] + f[1] + f[2] + f[3], f1 = mu * (f[0] - f[1]), f2 = mu * (f[2] - f[3]);
-        if (fn != 0.0f) {   // J' f: the contact force as a spatial force about the tree COM, dotted with cdof along the chain
-          const int nanc = con_nanc[cs];
+        if (fn != 0.0f) {
+          has = true;
           const v3 F = mk3(con_fr[cs][0], con_fr[cs][1], con_fr[cs][2]) * fn + mk3(con_fr[cs][3], con_fr[cs][4], con_fr[cs][5]) * f1 +
                        mk3(con_fr[cs][6], con_fr[cs][7], con_fr[cs][8]) * f2;
           const v3 tau = cross(mk3(con_off[cs][0], con_off[cs][1], con_off[cs][2]), F);
+          W[0] = tau.x; W[1] = tau.y; W[2] = tau.z; W[3] = F.x; W[4] = F.y; W[5] = F.z;
+        }
+      }
+      const int leaf = chain_at(cs, 0);
+      unsigned long long mask = __ballot(has);
+      while (mask) {
+        const int l = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        float w[6];
 #pragma unroll
-          for (int p0 = 0; p0 < 36; p0 += 4) {
-            if (__any(p0 < nanc)) {
+        for (int k = 0; k < 6; ++k) w[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(W[k]), l));
+        const int ld = __builtin_amdgcn_readlane(leaf, l);
 #pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                const int p = p0 + u;
-                if (p < nanc) {
-                  const int dd = chain_at(cs, p);
-                  const float* cd = s_cdof + 6 * dd;
-                  atomicAdd(s_y + dd, dot(ld3(cd), tau) + dot(ld3(cd + 3), F));
-                }
-              }
-            }
-          }
+        for (int s = 0; s < NVS; ++s) {
+          const int d = lane + RR_LANES * s;
+          if (d <= ld && ld <= (opaque(dofc1[s]) >> 16))
+            qc[s] += cd[s][0] * w[0] + cd[s][1] * w[1] + cd[s][2] * w[2] + cd[s][3] * w[3] + cd[s][4] * w[4] + cd[s][5] * w[5];
         }
       }
     }
-    sync();
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
-      const int d = lane + RR_LANES * s;
-      float qc = d < D.nv ? s_y[d] : 0.0f;
+      float qcs = qc[s];
       if (lim_act[s] && lim_jar[s] < 0) {
         const float f = -lim_D[s] * lim_jar[s];
         part[0] += lim_D[s] * lim_jar[s] * lim_jar[s];
-        qc += lim_sign[s] * f;
+        qcs += lim_sign[s] * f;
       }
-      qfrc_con[s] = qc;
+      qfrc_con[s] = qcs;
       part[1] += (Ma[s] - qfrc_smooth[s]) * (qacc[s] - qacc_smooth[s]);
     }
-    sync();
     wave_sum_n<2>(part);
     gauss = 0.5f * part[1];
     prev_cost = cost;
