@@ -32,6 +32,7 @@ struct rr_model {
   std::vector<int32_t> dbg_off, dbg_size;
   std::vector<const char*> dbg_cnames;
   int NBS, NVS, NCS;
+  bool stage_ok = true;
 
   const Entry* find(const char* n) const { auto it = e.find(n); return it == e.end() ? nullptr : &it->second; }
   int iscalar(const char* n) const { const Entry* x = find(n); return x ? ((const int32_t*)x->data)[0] : 0; }
@@ -54,6 +55,8 @@ static void layout(rr_model* m) {
   k.nJ = jadr[d.ncon];
   k.o_vec = take(d.nv); k.o_x = take(d.nv); k.o_y = take(d.nv); k.o_arm = take(2 * d.nv); k.o_warm = take(d.nv); k.o_qact = take(d.nv); k.o_base = take(d.nv);
   k.lds_floats = o;
+  // staging of the line search's compacted rows: cinert | cvel | pose regions each hold 4*ncon + nv floats
+  m->stage_ok = 4 * d.ncon + d.nv <= std::min(std::min(10 * d.nbody, 6 * d.nbody), std::max(7 * d.nbody + 4, 6 * d.nv));
   // debug dump
   int g = 0;
   auto dbg = [&](const char* name, int n) { int r = g; m->dbg_names.push_back(name); m->dbg_off.push_back(g); m->dbg_size.push_back(n); g += n; return r; };
@@ -238,6 +241,7 @@ extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t devi
 #undef UP
   if ((rc = upload_levels(b, "k_factor3", &b->T.factor3)) || (rc = upload_levels(b, "k_linv", &b->T.linv))) { rr_batch_destroy(b); return rc; }
   kern_t kern = pick_kernel(m->NBS, m->NVS, m->NCS);
+  if (!m->stage_ok) { rr_batch_destroy(b); return fail(RR_EUNSUPPORTED, "rr_batch_create: 4*ncon + nv exceeds the line-search staging cells (6*nbody)"); }
   if (m->dims.lds_bytes > 64 * 1024) { rr_batch_destroy(b); return fail(RR_EUNSUPPORTED, "rr_batch_create: per-env working set exceeds 160 KiB LDS"); }
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, m->dims.lds_bytes);
   if (e != hipSuccess) { rr_batch_destroy(b); return fail(RR_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }

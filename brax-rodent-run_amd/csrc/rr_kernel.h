@@ -135,43 +135,33 @@ __device__ __forceinline__ float dot6(const float* a, const float* b) {
   s += a[1] * b[1]; s += a[2] * b[2]; s += a[3] * b[3]; s += a[4] * b[4]; s += a[5] * b[5];
   return s;
 }
-// Wavefront sum, result in every lane.  Four DPP adds give each 16-lane row its total (no LDS crossbar),
-// then the four row totals are read back with v_readlane and added in a fixed order: deterministic, and
-// ~10 VALU issues instead of six dependent ds_bpermute round trips.
+// Wavefront sum, result in every lane.  Four DPP adds give each 16-lane row its total (no LDS crossbar), two row
+// broadcasts fold the rows into lane 63, one v_readlane returns it: a fixed order (deterministic), 7 issues per value.
 __device__ __forceinline__ float dpp_add(float v, const int ctrl_tag) {
   int x = __float_as_int(v), y;
   switch (ctrl_tag) {
     case 0: y = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true); break;    // quad_perm [1,0,3,2]
     case 1: y = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true); break;    // quad_perm [2,3,0,1]
     case 2: y = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true); break;   // row_half_mirror
-    default: y = __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true); break;  // row_mirror
+    case 3: y = __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true); break;   // row_mirror: every lane holds its row's sum
+    case 4: y = __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false); break;  // row_bcast15 -> rows 1, 3 add rows 0, 2
+    default: y = __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false); break; // row_bcast31 -> rows 2, 3 add rows 0+1
   }
   return v + __int_as_float(y);
 }
+// sum over the 64 lanes, returned wave-uniform: six DPP adds leave the total in lane 63
 __device__ __forceinline__ float wave_sum(float v) {
-  v = dpp_add(v, 0); v = dpp_add(v, 1); v = dpp_add(v, 2); v = dpp_add(v, 3);
-  const int x = __float_as_int(v);
-  const float r0 = __int_as_float(__builtin_amdgcn_readlane(x, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(x, 16));
-  const float r2 = __int_as_float(__builtin_amdgcn_readlane(x, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(x, 48));
-  return (r0 + r1) + (r2 + r3);
+  v = dpp_add(v, 0); v = dpp_add(v, 1); v = dpp_add(v, 2); v = dpp_add(v, 3); v = dpp_add(v, 4); v = dpp_add(v, 5);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 template <int K>
 __device__ __forceinline__ void wave_sum_n(float* v) {
 #pragma unroll
-  for (int k = 0; k < K; ++k) v[k] = dpp_add(v[k], 0);
+  for (int st = 0; st < 6; ++st)
 #pragma unroll
-  for (int k = 0; k < K; ++k) v[k] = dpp_add(v[k], 1);
+    for (int k = 0; k < K; ++k) v[k] = dpp_add(v[k], st);
 #pragma unroll
-  for (int k = 0; k < K; ++k) v[k] = dpp_add(v[k], 2);
-#pragma unroll
-  for (int k = 0; k < K; ++k) v[k] = dpp_add(v[k], 3);
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const int x = __float_as_int(v[k]);
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(x, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(x, 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(x, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(x, 48));
-    v[k] = (r0 + r1) + (r2 + r3);
-  }
+  for (int k = 0; k < K; ++k) v[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[k]), 63));
 }
 
 // solver impedance [UP mjx constraint._kbi]
@@ -1202,29 +1192,19 @@ struct Wave {
     update_constraint();
   }
 
-  // line-search point(s): cost and derivatives of the piecewise-quadratic 1-D cost at alpha
+  // line-search point(s): cost and derivatives of the piecewise-quadratic 1-D cost at alpha, over the COMPACTED active
+  // rows (see linesearch): row r*64 + lane of the first R rows; padding rows are (0, 0, 0) and never active
+  static constexpr int KR = 4 * NCS + NVS;     // row slots per lane if every contact / limit row were active
   template <int NP>
-  __device__ __forceinline__ void ls_eval(const float* alpha, const float* qg, LSPoint* out) {
+  __device__ __forceinline__ void ls_eval(const float* alpha, const float* qg, LSPoint* out, int R, const float* rjr, const float* rjv,
+                                          const float* rD) {
     float q[3 * NP];
 #pragma unroll
     for (int i = 0; i < 3 * NP; ++i) q[i] = 0.0f;
 #pragma unroll
-    for (int cs = 0; cs < NCS; ++cs) {
-      if (con_act[cs]) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float jr = con_jar[cs][k], jv = con_jv[cs][k], Dv = con_D[cs];
-          const float q0 = 0.5f * jr * jr * Dv, q1 = jv * jr * Dv, q2 = 0.5f * jv * jv * Dv;
-#pragma unroll
-          for (int i = 0; i < NP; ++i)
-            if (jr + alpha[i] * jv < 0) { q[3 * i] += q0; q[3 * i + 1] += q1; q[3 * i + 2] += q2; }
-        }
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < NVS; ++s) {
-      if (lim_act[s]) {
-        const float jr = lim_jar[s], jv = lim_jv[s], Dv = lim_D[s];
+    for (int r = 0; r < KR; ++r) {
+      if (r * RR_LANES < R) {
+        const float jr = rjr[r], jv = rjv[r], Dv = rD[r];
         const float q0 = 0.5f * jr * jr * Dv, q1 = jv * jr * Dv, q2 = 0.5f * jv * jv * Dv;
 #pragma unroll
         for (int i = 0; i < NP; ++i)
@@ -1243,7 +1223,11 @@ struct Wave {
     }
   }
 
-  // [UP mjx solver._linesearch]
+  // [UP mjx solver._linesearch].  Only the ACTIVE constraint rows (contacts in penetration x 4 pyramid rows, violated
+  // limits) enter the 1-D cost, typically a few dozen of the 4*ncon + nv candidates, scattered over the lanes.  Their
+  // (Jaref, Jv, D) triples are compacted once per line search through LDS (positions by ballot / mbcnt; the staging cells
+  // are the dead cinert / cvel / pose regions), so that every evaluation of the up to 2 + 3*ls_iterations points costs one
+  // row per lane instead of 4*NCS + NVS.
   __device__ __forceinline__ void linesearch() {
     float red[4] = {0, 0, 0, 0};
     put_vec(search);   // mv = M search is carried by the caller's recurrence
@@ -1257,15 +1241,46 @@ struct Wave {
       red[2] += search[s] * qfrc_smooth[s];
       red[3] += search[s] * mv[s];
     }
+    int R = 0;
+    {
+      float* const st_jr = s_cinert; float* const st_jv = s_cvel; float* const st_D = s_buf;
+#pragma unroll
+      for (int cs = 0; cs < NCS; ++cs) {
+        const unsigned long long m = __ballot(con_act[cs]);
+        const int pos = R + 4 * (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        R += 4 * __popcll(m);
+        if (con_act[cs]) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { st_jr[pos + k] = con_jar[cs][k]; st_jv[pos + k] = con_jv[cs][k]; st_D[pos + k] = con_D[cs]; }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < NVS; ++s) {
+        const unsigned long long m = __ballot(lim_act[s]);
+        const int pos = R + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        R += __popcll(m);
+        if (lim_act[s]) { st_jr[pos] = lim_jar[s]; st_jv[pos] = lim_jv[s]; st_D[pos] = lim_D[s]; }
+      }
+    }
+    sync();
+    float rjr[KR], rjv[KR], rD[KR];
+#pragma unroll
+    for (int r = 0; r < KR; ++r) {
+      rjr[r] = rjv[r] = rD[r] = 0.0f;
+      if (r * RR_LANES < R) {
+        const int idx = r * RR_LANES + lane;
+        if (idx < R) { rjr[r] = s_cinert[idx]; rjv[r] = s_cvel[idx]; rD[r] = s_buf[idx]; }
+      }
+    }
     wave_sum_n<4>(red);
     const float smag = sqrtf(red[0]) * D.meaninertia * (float)(D.nv > 1 ? D.nv : 1);
     const float gtol = D.tolerance * D.ls_tolerance * smag;
     const float qg[3] = {gauss, red[1] - red[2], 0.5f * red[3]};
     LSPoint p0, lo, hi, tmp3[3];
     float a1[1] = {0.0f};
-    ls_eval<1>(a1, qg, &p0);
+    ls_eval<1>(a1, qg, &p0, R, rjr, rjv, rD);
     a1[0] = p0.alpha - p0.d0 / p0.d1;
-    ls_eval<1>(a1, qg, &lo);
+    ls_eval<1>(a1, qg, &lo, R, rjr, rjv, rD);
     if (lo.d0 < p0.d0) { hi = p0; } else { hi = lo; lo = p0; }
     bool swap = true;
     for (int it = 0; it < D.ls_iterations; ++it) {
@@ -1274,8 +1289,7 @@ struct Wave {
       done |= (hi.d0 > 0) && (hi.d0 < gtol);
       if (uni(done)) break;
       const float a3[3] = {lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, 0.5f * (lo.alpha + hi.alpha)};
-      for (int rep = 0; rep < RR_REP_LSEVAL; ++rep) { ls_eval<3>(a3, qg, tmp3); asm volatile("" :: "v"(tmp3[0].cost), "v"(tmp3[1].cost), "v"(tmp3[2].cost)); }
-      ls_eval<3>(a3, qg, tmp3);
+      ls_eval<3>(a3, qg, tmp3, R, rjr, rjv, rD);
       const LSPoint lo_next = tmp3[0], hi_next = tmp3[1], mid = tmp3[2];
       const bool swap_lo_next = (lo.d0 > 0) || (lo.d0 < lo_next.d0);
       if (swap_lo_next) lo = lo_next;
@@ -1441,10 +1455,6 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
     w.qacc[s] = w.Ma[s] = w.grad[s] = w.Mgrad[s] = w.search[s] = w.mv[s] = w.qfrc_con[s] = 0.0f;
   }
   for (int i = lane; i < D.nv; i += RR_LANES) { w.s_arm[i] = T.dof_f[16 * i]; w.s_base[i] = T.dof_base[i]; }
-  if (lane == 0) {  // world body entries that no phase overwrites
-    for (int k = 0; k < 6; ++k) w.s_cvel[k] = 0.0f;
-    for (int k = 0; k < 10; ++k) w.s_cinert[k] = 0.0f;
-  }
   w.sync();
 
   if (PROF) { for (int i = 0; i < RR_NPH; ++i) w.pt[i] = 0; w.pt_last = __builtin_readcyclecounter(); }
@@ -1471,7 +1481,9 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
         w.blast[s] = ok ? T.body_i[RR_BODYI * b + 10] : 0;
       }
     }
-    if (lane == 0) {  // world body pose (its LDS cells are reused by later phases of every substep)
+    if (lane == 0) {  // world body entries (their LDS cells are reused by later phases of every substep)
+      for (int k = 0; k < 6; ++k) w.s_cvel[k] = 0.0f;
+      for (int k = 0; k < 10; ++k) w.s_cinert[k] = 0.0f;
       for (int k = 0; k < 3; ++k) w.s_xpos[k] = 0.0f;
       w.s_xquat[0] = 1.0f; w.s_xquat[1] = w.s_xquat[2] = w.s_xquat[3] = 0.0f;
     }
