@@ -20,6 +20,8 @@
 #define RR_DOFI 12   // ints per dof in k_dof_i
 #define RR_BODYI 12  // ints per body in k_body_i
 #define RR_PF 4      // table rows kept in flight by the level-parallel factor / solve loops
+#define RR_BLK 2     // rows per block of the level schedules (ktables BLK): their LDS reads are issued together
+#define RR_RING 8    // rows of a level schedule in flight (ktables RING)
 #define RR_U 8       // lane tables are consumed in batches of RR_U rows: their loads are issued together
 #define RR_NPH 16    // phases of the diagnostic (s_memtime) build
 #ifndef RR_EXP
@@ -701,30 +703,30 @@ struct Wave {
   __device__ __forceinline__ void run_levels(rr_gi table, int nrows) {
     typedef const unsigned long long __attribute__((address_space(1)))* rr_gu64;
     rr_gu64 tab = (rr_gu64)table;
-    int2 ring[2 * RR_PF];      // two blocks in flight: the L2 latency of the table stream exceeds one block of LDS work
+    int2 ring[RR_RING];        // rows in flight: the L2 latency of the table stream exceeds one block of LDS work
 #pragma unroll
-    for (int u = 0; u < 2 * RR_PF; ++u) { const unsigned long long q_ = tab[u * RR_LANES + lane]; ring[u].x = (int)(unsigned)q_; ring[u].y = (int)(q_ >> 32); }
+    for (int u = 0; u < RR_RING; ++u) { const unsigned long long q_ = tab[u * RR_LANES + lane]; ring[u].x = (int)(unsigned)q_; ring[u].y = (int)(q_ >> 32); }
     float acc = 0.0f;
-    for (int r0 = 0; r0 < nrows; r0 += 2 * RR_PF) {
+    for (int r0 = 0; r0 < nrows; r0 += RR_RING) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        int2 e[RR_PF];
+      for (int h = 0; h < RR_RING / RR_BLK; ++h) {
+        int2 e[RR_BLK];
 #pragma unroll
-        for (int u = 0; u < RR_PF; ++u) {
-          e[u] = ring[h * RR_PF + u];
-          const unsigned long long q_ = tab[(r0 + (2 + h) * RR_PF + u) * RR_LANES + lane];
-          ring[h * RR_PF + u].x = (int)(unsigned)q_; ring[h * RR_PF + u].y = (int)(q_ >> 32);
+        for (int u = 0; u < RR_BLK; ++u) {
+          e[u] = ring[h * RR_BLK + u];
+          const unsigned long long q_ = tab[(r0 + RR_RING + h * RR_BLK + u) * RR_LANES + lane];
+          ring[h * RR_BLK + u].x = (int)(unsigned)q_; ring[h * RR_BLK + u].y = (int)(q_ >> 32);
         }
-        float va[RR_PF], vb[RR_PF], vp[RR_PF], vo[RR_PF];
+        float va[RR_BLK], vb[RR_BLK], vp[RR_BLK], vo[RR_BLK];
 #pragma unroll
-        for (int u = 0; u < RR_PF; ++u) {
+        for (int u = 0; u < RR_BLK; ++u) {
           const int a4 = e[u].x & 0xFFFF;
           va[u] = lds_ld(a4); vb[u] = lds_ld((int)((unsigned)e[u].x >> 16));
           vp[u] = DIV ? lds_ld(a4 - ((e[u].y >> 16) & 0xFF) + 4) : 1.0f;
           vo[u] = lds_ld(e[u].y & 0xFFFF);
         }
 #pragma unroll
-        for (int u = 0; u < RR_PF; ++u) {
+        for (int u = 0; u < RR_BLK; ++u) {
           float t = va[u];
           if (DIV) { float r = __builtin_amdgcn_rcpf(vp[u]); r = r * (2.0f - vp[u] * r); t *= r; }
           if (DIV) {       // several contribution ranks per target: accumulate, apply on the flagged row
@@ -734,7 +736,7 @@ struct Wave {
             lds_st(e[u].y & 0xFFFF, vo[u] - vb[u] * t);
           }
         }
-        if ((__builtin_amdgcn_readfirstlane(e[RR_PF - 1].y) >> 24) & 2) sync();
+        if ((__builtin_amdgcn_readfirstlane(e[RR_BLK - 1].y) >> 24) & 2) sync();
       }
     }
   }

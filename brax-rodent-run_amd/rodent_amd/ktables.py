@@ -318,13 +318,15 @@ def build_kernel_tables(m):
     # sum to d, 2 = level ends (LDS hand-off); they are the same in all 64 lanes of a row.
     ZERO, TRASH = nM, nM + 2
 
+    BLK, RING = 2, 8          # rows per block (RR_BLK), rows in flight (RR_RING)
+
     def pack_levels(levels):
         rows = []
         for lv in levels:
             if not lv:
                 continue
             lv = list(lv)
-            while len(lv) % PF:
+            while len(lv) % BLK:
                 lv.append(([], 0))
             for t, (ops, fl) in enumerate(lv):
                 if t == len(lv) - 1:
@@ -341,10 +343,10 @@ def build_kernel_tables(m):
         empty = np.zeros((LANES, 2), np.int64)
         empty[:, 0] = ZERO | (ZERO << 16)
         empty[:, 1] = TRASH
-        while len(rows) % (2 * PF):                               # the kernel consumes two blocks per loop trip
+        while len(rows) % RING:                               # the kernel consumes two blocks per loop trip
             rows.append(empty)
         nrows = len(rows)
-        rows += [empty] * (2 * PF)                                # slack blocks the ring may prefetch
+        rows += [empty] * RING                                # slack blocks the ring may prefetch
         return np.stack(rows).astype(np.int32), np.int32(nrows)
 
     # factorisation [MuJoCo mj_factorM], deep -> shallow: the rank-1 updates of a level are grouped by TARGET entry.  A lane

@@ -90,5 +90,5 @@ def test_env_step_matches_oracle(oracle_built):
         assert np.median(np.abs(nstate.obs[e].cpu().numpy() - obs) / scale) < 1e-4
     print("max |qpos - oracle f64| per env after 1 env-step:", np.array2string(np.array(errs), precision=2))
     print("oracle f32 vs f64 gap per env:                 ", np.array2string(np.array(gaps), precision=2))
-    # HIP float32 must sit as close to the float64 truth as the scalar float32 oracle does (x10 margin, floor 2e-5)
-    assert np.all(np.array(errs) <= 10 * np.array(gaps) + 2e-5)
+    # HIP float32 must sit as close to the float64 truth as the scalar float32 oracle does (tests/util.py assert_f32_class)
+    print("geometric mean of err / gap:", util.assert_f32_class(errs, gaps))

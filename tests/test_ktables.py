@@ -46,7 +46,8 @@ def test_mulm_table(model_and_state):
     np.testing.assert_allclose(y[:nv], Md @ x, rtol=1e-12, atol=1e-14)
 
 
-PF = 4
+PF = 2          # rows per block of the level schedules (RR_BLK)
+RING = 8        # rows in flight (RR_RING)
 
 
 def run_levels(L, tab, nrows, div):
@@ -57,7 +58,7 @@ def run_levels(L, tab, nrows, div):
     assert L[nM] == 0.0 and L[nM + 1] == 1.0
     acc = np.zeros(LANES)
     written, read = set(), set()
-    assert nrows % (2 * PF) == 0 and tab.shape[0] == nrows + 2 * PF
+    assert nrows % RING == 0 and tab.shape[0] == nrows + RING
     assert np.all(tab[nrows:, :, 0] == (nM | nM << 16)) and np.all(tab[nrows:, :, 1] == nM + 2)
     for b0 in range(0, nrows, PF):
         snap = L.copy()                                   # what the block's batched reads see
