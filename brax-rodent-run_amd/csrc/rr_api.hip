@@ -51,9 +51,7 @@ static void layout(rr_model* m) {
   k.o_cdof = take(6 * d.nv); k.o_cvel = take(6 * d.nbody);
   k.o_qM = take(d.nM);
   k.o_qLD = take(std::max(std::max(d.nM + 3, 12 * d.nbody), 2 * d.nv));   // also cacc | cfrc and the sin/cos scratch
-  const int32_t* jadr = (const int32_t*)m->find("con_jadr")->data;
-  k.nJ = jadr[d.ncon];
-  k.o_vec = take(d.nv); k.o_x = take(d.nv); k.o_y = take(d.nv); k.o_arm = take(2 * d.nv); k.o_warm = take(d.nv); k.o_qact = take(d.nv); k.o_base = take(d.nv);
+  k.o_vec = take(d.nv); k.o_x = take(d.nv); k.o_arm = take(2 * d.nv); k.o_warm = take(d.nv); k.o_qact = take(d.nv); k.o_base = take(d.nv);
   k.lds_floats = o;
   // staging of the line search's compacted rows: cinert | cvel | pose regions each hold 4*ncon + nv floats
   m->stage_ok = 4 * d.ncon + d.nv <= std::min(std::min(10 * d.nbody, 6 * d.nbody), std::max(7 * d.nbody + 4, 6 * d.nv));
@@ -105,9 +103,9 @@ extern "C" int rr_model_load(const char* path, rr_model** out) {
     m->e[name] = e;
   }
   static const char* need[] = {"nq", "nv", "nu", "nbody", "njnt", "ngeom", "nM", "ncon", "nlimit", "nefc", "obs_dim", "k_slots",
-                               "k_lvl_adr", "k_lvl_body", "k_child", "k_body_i", "k_body_f", "k_jnt_i", "k_jnt_f", "k_dof_i",
-                               "k_dof_f", "k_act_f", "k_M_ij_k", "k_M_rowadr", "k_tri", "k_mulm", "k_solve_fwd", "k_solve_bwd",
-                               "k_solve_bwd_adr", "k_solve_bwd_level", "k_bwd_steps", "k_body_anc", "k_nround", "k_con_chain_bytes", "k_solve2", "k_solve_seq", "k_factor3", "k_factor3_rows", "k_linv", "k_coljob", "k_rowjob", "k_rowjob_chain", "k_jobown", "k_solve_lmax", "k_linv_rows", "k_dof_chain", "k_dof_base", "k_factor2", "k_factor2_first", "k_factor2_rows", "k_con_i", "k_con_f", "k_con_chain", "k_jtf", "k_root_mass", "con_jadr",
+                               "k_body_i", "k_body_f", "k_jnt_i", "k_jnt_f", "k_dof_i", "k_dof_f", "k_act_f", "k_M_ij_k", "k_body_anc",
+                               "k_nround", "k_factor3", "k_factor3_rows", "k_linv", "k_linv_rows", "k_coljob", "k_rowjob", "k_rowjob_chain",
+                               "k_jobown", "k_solve_lmax", "k_dof_base", "k_con_i", "k_con_f", "k_con_chain_packed", "k_root_mass",
                                "dof_depth", "body_depth", "opt_timestep", "opt_gravity", "stat_meaninertia"};
   for (const char* nme : need)
     if (!m->find(nme)) { std::string s = std::string("rr_model_load: blob lacks '") + nme + "'"; delete m; return fail(RR_EIO, s); }
@@ -123,22 +121,17 @@ extern "C" int rr_model_load(const char* path, rr_model** out) {
   RRDims& k = m->kd;
   memset(&k, 0, sizeof(k));
   k.nq = d.nq; k.nv = d.nv; k.nu = d.nu; k.nbody = d.nbody; k.njnt = d.njnt; k.nM = d.nM; k.ncon = d.ncon;
-  const Entry* la = m->find("k_lvl_adr");
-  k.nlevel = (int)la->count - 2;
   int dmax = 0;
   { const Entry* dd = m->find("dof_depth"); for (size_t i = 0; i < dd->count; ++i) dmax = std::max(dmax, ((const int32_t*)dd->data)[i]); }
   k.dmax = dmax;
   k.nroot = (int)m->find("k_root_mass")->count;
-  k.ntri = (int)m->find("k_tri")->count;
-  k.nbwd = (int)m->find("k_bwd_steps")->count;
   k.nround = m->iscalar("k_nround");
   k.ninv = m->iscalar("k_linv_rows");
   if (d.nM > RR_LANES * (m->NVS == 1 ? 10 : (m->NVS == 2 ? 18 : 35))) { delete m; return fail(RR_EUNSUPPORTED, "rr_model_load: more mass-matrix entries than the kernel's register table"); }
-  k.nchain = (int)m->find("k_con_chain_bytes")->count;
-  k.nment = (d.nM + RR_LANES - 1) / RR_LANES;
   k.nfac = m->iscalar("k_factor3_rows");
-  if (m->find("k_solve2")->dims[1] != m->NVS * RR_LANES) { delete m; return fail(RR_EUNSUPPORTED, "rr_model_load: level-solve table wider than the kernel instance"); }
-  k.T_mulm = m->find("k_mulm")->dims[0]; k.T_jtf = m->find("k_jtf")->dims[0]; k.T_chain = m->find("k_con_chain")->dims[0];
+  { const int njs = (m->NVS >= 3 ? m->NVS + 1 : m->NVS) * RR_LANES;     // Wave::NJS job slots
+    if ((int)m->find("k_coljob")->count != njs || (int)m->find("k_rowjob")->count != njs || m->iscalar("k_solve_lmax") > 16) {
+      delete m; return fail(RR_EIO, "rr_model_load: solve job tables do not match the kernel instance (stale blob)"); } }
   k.obs_dim = d.obs_dim; k.iterations = d.iterations; k.ls_iterations = d.ls_iterations;
   k.dt = d.timestep; k.gx = m->fscalar("opt_gravity", 0); k.gy = m->fscalar("opt_gravity", 1); k.gz = m->fscalar("opt_gravity", 2);
   k.tolerance = m->fscalar("opt_tolerance"); k.ls_tolerance = m->fscalar("opt_ls_tolerance");
@@ -147,9 +140,7 @@ extern "C" int rr_model_load(const char* path, rr_model** out) {
   if (m->find("k_dof_i")->dims[1] != RR_DOFI) { delete m; return fail(RR_EIO, "rr_model_load: k_dof_i width mismatch (stale blob)"); }
   if (m->find("k_body_i")->dims[1] != RR_BODYI) { delete m; return fail(RR_EIO, "rr_model_load: k_body_i width mismatch (stale blob)"); }
   if (d.nv > 256 || d.ncon > 256) { delete m; return fail(RR_EUNSUPPORTED, "rr_model_load: nv/ncon above the 8-bit table index"); }
-  if (m->find("k_mulm")->dims[1] != m->NVS * RR_LANES || m->find("k_con_chain")->dims[1] != m->NCS * RR_LANES) {
-    delete m; return fail(RR_EIO, "rr_model_load: lane-table width mismatch");
-  }
+  if (m->find("k_con_chain_packed")->dims[1] != m->NCS * RR_LANES) { delete m; return fail(RR_EIO, "rr_model_load: lane-table width mismatch"); }
   layout(m);
   *out = m;
   return RR_OK;
@@ -233,10 +224,9 @@ extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t devi
   b->m = m; b->N = num_envs; b->device = device; b->stream = (hipStream_t)stream; b->kd = m->kd;
   int rc = 0;
 #define UP(field, name) if ((rc = upload(b, name, &b->T.field))) { rr_batch_destroy(b); return rc; }
-  UP(lvl_adr, "k_lvl_adr") UP(lvl_body, "k_lvl_body") UP(child, "k_child") UP(body_i, "k_body_i") UP(jnt_i, "k_jnt_i")
-  UP(dof_i, "k_dof_i") UP(M_ij_k, "k_M_ij_k") UP(M_rowadr, "k_M_rowadr") UP(tri, "k_tri") UP(mulm, "k_mulm")
-  UP(solve_fwd, "k_solve_fwd") UP(solve_bwd, "k_solve_bwd") UP(solve_bwd_adr, "k_solve_bwd_adr") UP(solve_bwd_level, "k_solve_bwd_level") UP(bwd_steps, "k_bwd_steps") UP(body_anc, "k_body_anc") UP(con_chain_packed, "k_con_chain_packed") UP(solve2, "k_solve2") UP(solve_seq, "k_solve_seq")  UP(coljob, "k_coljob") UP(rowjob, "k_rowjob") UP(rowjob_chain, "k_rowjob_chain") UP(jobown, "k_jobown") UP(dof_chain, "k_dof_chain") UP(dof_base, "k_dof_base") UP(factor2, "k_factor2") UP(factor2_first, "k_factor2_first")  UP(con_i, "k_con_i")
-  UP(con_chain, "k_con_chain") UP(jtf, "k_jtf") UP(body_f, "k_body_f") UP(jnt_f, "k_jnt_f") UP(dof_f, "k_dof_f")
+  UP(body_i, "k_body_i") UP(jnt_i, "k_jnt_i") UP(dof_i, "k_dof_i") UP(M_ij_k, "k_M_ij_k")
+  UP(body_anc, "k_body_anc") UP(con_chain_packed, "k_con_chain_packed") UP(coljob, "k_coljob") UP(rowjob, "k_rowjob") UP(rowjob_chain, "k_rowjob_chain") UP(jobown, "k_jobown") UP(dof_base, "k_dof_base") UP(con_i, "k_con_i")
+  UP(body_f, "k_body_f") UP(jnt_f, "k_jnt_f") UP(dof_f, "k_dof_f")
   UP(act_f, "k_act_f") UP(con_f, "k_con_f") UP(root_mass, "k_root_mass")
 #undef UP
   if ((rc = upload_levels(b, "k_factor3", &b->T.factor3)) || (rc = upload_levels(b, "k_linv", &b->T.linv))) { rr_batch_destroy(b); return rc; }

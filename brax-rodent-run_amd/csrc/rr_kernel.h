@@ -19,42 +19,31 @@
 #define RR_LANES 64
 #define RR_DOFI 12   // ints per dof in k_dof_i
 #define RR_BODYI 12  // ints per body in k_body_i
-#define RR_PF 4      // table rows kept in flight by the level-parallel factor / solve loops
 #define RR_BLK 2     // rows per block of the level schedules (ktables BLK): their LDS reads are issued together
 #define RR_RING 8    // rows of a level schedule in flight (ktables RING)
-#define RR_U 8       // lane tables are consumed in batches of RR_U rows: their loads are issued together
 #define RR_NPH 16    // phases of the diagnostic (s_memtime) build
-#ifndef RR_EXP
-#define RR_EXP 0
-#endif
-#if RR_EXP == 1
-#define RR_SOLVE_ADD(p, v) (*(p) = (v))      /* timing experiment: plain store instead of the LDS atomic */
-#else
-#define RR_SOLVE_ADD(p, v) atomicAdd((p), (v))
-#endif
 #define RR_MINVAL 1e-15f
 #define RR_MINIMP 0.0001f
 #define RR_MAXIMP 0.9999f
 
 struct RRDims {
-  int nq, nv, nu, nbody, njnt, nM, ncon, nlevel, dmax, nroot;
-  int T_mulm, T_jtf, T_chain, obs_dim, iterations, ls_iterations, nJ, ntri, nbwd, nfac, nround, nchain, nment, ninv;
+  int nq, nv, nu, nbody, njnt, nM, ncon, dmax, nroot;
+  int obs_dim, iterations, ls_iterations, nfac, nround, ninv;
   float dt, gx, gy, gz, tolerance, ls_tolerance, meaninertia;
   // LDS offsets (floats)
   int o_qpos, o_qvel, o_act, o_ctrl, o_xpos, o_xquat, o_cinert, o_cdof, o_cvel,
-      o_qM, o_qLD, o_vec, o_x, o_y, o_arm, o_chain, o_warm, o_qact, o_base, lds_floats;
+      o_qM, o_qLD, o_vec, o_x, o_arm, o_warm, o_qact, o_base, lds_floats;
   // debug dump offsets (floats)
   int g_xpos, g_xquat, g_xmat, g_com, g_cinert, g_crb, g_cdof, g_cvel, g_cfrc, g_qM, g_qLD, g_dinv, g_bias, g_passive,
       g_actuator, g_smooth, g_qacc_smooth, g_con_dist, g_con_pos, g_con_frame, g_con_D, g_con_aref, g_lim, g_qacc,
-      g_qfrc_constraint, g_misc, g_J, dbg_floats;
+      g_qfrc_constraint, g_misc, dbg_floats;
 };
 
 // Table pointers carry the global address space in their type, so every table access is a global_load (never flat).
 typedef const int __attribute__((address_space(1)))* rr_gi;
 typedef const float __attribute__((address_space(1)))* rr_gf;
 struct RRTables {
-  rr_gi factor3, linv, coljob, rowjob, rowjob_chain, jobown, dof_chain, dof_base, lvl_adr, lvl_body, child, body_i, jnt_i, dof_i, M_ij_k, M_rowadr, tri, mulm, solve_fwd, solve_bwd,
-      solve_bwd_adr, solve_bwd_level, bwd_steps, body_anc, con_chain_packed, solve2, solve_seq, factor2, factor2_first, con_i, con_chain, jtf;
+  rr_gi factor3, linv, coljob, rowjob, rowjob_chain, jobown, dof_base, body_i, jnt_i, dof_i, M_ij_k, body_anc, con_chain_packed, con_i;
   rr_gf body_f, jnt_f, dof_f, act_f, con_f, root_mass;
 };
 
@@ -267,7 +256,7 @@ struct Wave {
   // consumed / written out), s_cacc|s_cfrc and the sin/cos scratch live in the region that later holds qLD,
   // s_buf reuses xpos|xquat after the contact geometry has been taken.
   float *s_qpos, *s_qvel, *s_act, *s_ctrl, *s_xpos, *s_xquat, *s_cinert, *s_crb, *s_cdof, *s_cvel, *s_cacc,
-      *s_cfrc, *s_buf, *s_sc, *s_qM, *s_qLD, *s_vec, *s_x, *s_y, *s_arm, *s_warm, *s_qact;
+      *s_cfrc, *s_buf, *s_sc, *s_qM, *s_qLD, *s_vec, *s_x, *s_arm, *s_warm, *s_qact;
   int* s_base;            // Madr + depth per dof (entry (i, j) of a descendant i of j sits at s_base[i] - depth[j])
 
   static constexpr int W = NVS * RR_LANES;
@@ -307,7 +296,7 @@ struct Wave {
     s_xpos = l + d.o_xpos; s_xquat = l + d.o_xquat; s_cinert = l + d.o_cinert; s_crb = s_cinert;
     s_cdof = l + d.o_cdof; s_cvel = l + d.o_cvel; s_qM = l + d.o_qM; s_qLD = l + d.o_qLD;
     s_cacc = s_qLD; s_cfrc = s_qLD + 6 * d.nbody; s_sc = s_qLD; s_buf = s_xpos;
-    s_vec = l + d.o_vec; s_x = l + d.o_x; s_y = l + d.o_y; s_arm = l + d.o_arm; s_warm = l + d.o_warm; s_qact = l + d.o_qact;
+    s_vec = l + d.o_vec; s_x = l + d.o_x; s_arm = l + d.o_arm; s_warm = l + d.o_warm; s_qact = l + d.o_qact;
     s_base = (int*)(l + d.o_base);
   }
 
@@ -316,11 +305,7 @@ struct Wave {
   // compiler keeps the program order of the LDS accesses around this point.
   // "memory" keeps the compiler from moving LDS accesses across; lgkmcnt(0) retires this wave's LDS operations
   // (incl. the float atomics) without draining outstanding global table prefetches (no vmcnt wait).
-#if RR_EXP == 2
-  __device__ __forceinline__ void sync() { asm volatile("" ::: "memory"); }   /* timing experiment: no LDS drain */
-#else
   __device__ __forceinline__ void sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
-#endif
   __device__ __forceinline__ v3 get_com(int r) const {
     return mk3(r ? com1[0] : com0[0], r ? com1[1] : com0[1], r ? com1[2] : com0[2]);
   }

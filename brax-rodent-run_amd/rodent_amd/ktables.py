@@ -15,7 +15,6 @@ from __future__ import annotations
 import numpy as np
 
 LANES = 64
-UNROLL = 8      # the kernel consumes lane tables in batches of 8 rows (loads issued together)
 
 
 def _slots(n):
@@ -33,25 +32,8 @@ def build_kernel_tables(m):
     k = {}
     k["k_slots"] = np.array([NBS, NVS, NCS], np.int32)
 
-    # ---- body levels (level 1 = children of world) and child lists
     depth = m["body_depth"]
     nlevel = int(depth.max())
-    order = sorted(range(1, nb), key=lambda b: (depth[b], b))
-    lvl_adr = np.zeros(nlevel + 2, np.int32)
-    for L in range(1, nlevel + 1):
-        lvl_adr[L + 1] = lvl_adr[L] + sum(1 for b in order if depth[b] == L)
-    if max(lvl_adr[L + 1] - lvl_adr[L] for L in range(1, nlevel + 1)) > LANES:
-        raise ValueError("more than 64 bodies on one tree level")
-    k["k_lvl_adr"] = lvl_adr
-    k["k_lvl_body"] = np.asarray(order, np.int32)
-    child_adr = np.zeros(nb + 1, np.int32)
-    child = []
-    for b in range(nb):
-        child_adr[b] = len(child)
-        child += [c for c in range(1, nb) if par[c] == b]
-    child_adr[nb] = len(child)
-    k["k_child_adr"] = child_adr
-    k["k_child"] = np.asarray(child, np.int32)
     # roots (kinematic trees) and their total mass
     roots = sorted(set(int(r) for r in m["body_rootid"][1:]))
     k["k_root"] = np.asarray(roots, np.int32)
@@ -73,7 +55,7 @@ def build_kernel_tables(m):
     for b in range(1, nb):
         assert par[b] < b and all(par[c] >= b or c > blast[b] for c in range(b + 1, nb) if c > blast[b] or True)
     k["k_body_i"] = np.stack([par, m["body_jntadr"], m["body_jntnum"], m["body_dofadr"], m["body_dofnum"],
-                              k["k_body_root"], child_adr[:-1], child_adr[1:] - child_adr[:-1], depth, sib,
+                              k["k_body_root"], np.zeros(nb, np.int32), np.zeros(nb, np.int32), depth, sib,
                               blast, np.zeros(nb, np.int32)], axis=1).astype(np.int32)   # 12 ints
     # pointer-doubling ancestor table: byte k of (anc[2b], anc[2b+1]) = 2^k-th ancestor of body b (0 = none / world)
     nround = max(1, int(np.ceil(np.log2(max(2, nlevel)))))
@@ -88,12 +70,6 @@ def build_kernel_tables(m):
         packed_anc[:, r // 4] |= anck[r] << (8 * (r % 4))
     k["k_body_anc"] = packed_anc.astype(np.uint32).view(np.int32)
     k["k_nround"] = np.int32(nround)
-    # backward-sweep schedule: (level, sibling rank) steps, deepest level first; level 1 bodies hang off the world
-    steps = []
-    for L in range(nlevel, 1, -1):
-        for r in range(int(max(sib[b] for b in range(1, nb) if depth[b] == L)) + 1):
-            steps.append(L | (r << 8))
-    k["k_bwd_steps"] = np.asarray(steps if steps else [0], np.int32)
     k["k_body_f"] = np.concatenate([m["body_pos"], m["body_quat"], m["body_ipos"], m["body_iquat"],
                                     m["body_mass"][:, None], m["body_inertia"]], axis=1)  # 18 floats
     qa = m["jnt_qposadr"]
@@ -149,169 +125,25 @@ def build_kernel_tables(m):
     # ---- sparse M: element -> (row dof i, col dof j), and row address of the column's own row
     anc_adr, anc = m["dof_ancadr"], m["dof_anc"]       # chain root..self
     M_ij = np.zeros(nM, np.int32)
-    M_rowadr = np.zeros(nM, np.int32)                  # for element (k, a_p): Madr[a_p]
     for i in range(nv):
         chain = anc[anc_adr[i]:anc_adr[i + 1]][::-1]   # self, parent, ..., root
         for p, j in enumerate(chain):
             M_ij[Madr[i] + p] = i | (int(j) << 16)
-            M_rowadr[Madr[i] + p] = Madr[j]
     # kernel layout: row | col << 8 per entry, padded with -1 to whole 64-lane rows plus one row of slack (prefetch)
     nrow = (nM + LANES - 1) // LANES + 1
     mk = np.full(nrow * LANES, -1, np.int32)
     mk[:nM] = (M_ij & 0xFFFF) | ((M_ij >> 16) << 8)
     k["k_M_ij"] = M_ij
     k["k_M_ij_k"] = mk
-    k["k_M_rowadr"] = M_rowadr
-    # triangular pair table for the factorisation: t -> (p, q), 1 <= p <= q, ordered by q then p
     dmax = int(ddepth.max())
-    tri = [(p | (q << 8)) for q in range(1, dmax + 1) for p in range(1, q + 1)]
-    k["k_tri"] = np.asarray(tri if tri else [0], np.int32)
-
-    W = NVS * LANES
-
-    def lane_table(rows):
-        """rows[d] = list of packed ints for dof d -> [T][W] table padded with -1."""
-        T = max(1, max((len(r) for r in rows), default=1))
-        T = (T + UNROLL - 1) // UNROLL * UNROLL
-        out = np.full((T, W), -1, np.int32)
-        for d, r in enumerate(rows):
-            for t, v in enumerate(r):
-                out[t, d] = v
-        return out
-
-    # ---- M*x: full symmetric row of dof i: (col, address)
-    rows = [[] for _ in range(nv)]
-    for i in range(nv):
-        chain = anc[anc_adr[i]:anc_adr[i + 1]][::-1]
-        for p, j in enumerate(chain):
-            rows[i].append(int(j) | ((Madr[i] + p) << 8))
-            if p > 0:
-                rows[int(j)].append(i | ((Madr[i] + p) << 8))
-    k["k_mulm"] = lane_table(rows)
-
-    # ---- L^-1 forward substitution by dof depth level: at step l every dof deeper than l
-    #      subtracts L[i, anc_l(i)] * x[anc_l(i)]   (chain[l] = ancestor at depth l)
-    ndl = dmax + 1
-    fwd = np.full((max(1, dmax), W), -1, np.int32)
-    for i in range(nv):
-        chain = anc[anc_adr[i]:anc_adr[i + 1]]         # root..self; chain[l] has depth l
-        for l in range(ddepth[i]):
-            j = int(chain[l])
-            fwd[l, i] = j | ((Madr[i] + (ddepth[i] - l)) << 8)
-    k["k_solve_fwd"] = fwd
-    # ---- L^-T backward substitution: levels deep -> shallow; dof j gathers its descendants at depth l
-    desc_by_level = [[[] for _ in range(nv)] for _ in range(ndl)]
-    for i in range(nv):
-        chain = anc[anc_adr[i]:anc_adr[i + 1]]
-        for l in range(ddepth[i]):
-            j = int(chain[l])
-            desc_by_level[ddepth[i]][j].append(i | ((Madr[i] + (ddepth[i] - l)) << 8))
-    bwd_rows, bwd_adr, bwd_level = [], [0], []
-    for l in range(dmax, 0, -1):
-        T = max(len(r) for r in desc_by_level[l])
-        for t in range(T):
-            bwd_level.append(l if t == 0 else -1)
-            row = np.full(W, -1, np.int32)
-            for j in range(nv):
-                if t < len(desc_by_level[l][j]):
-                    row[j] = desc_by_level[l][j][t]
-            bwd_rows.append(row)
-        bwd_adr.append(len(bwd_rows))
-    k["k_solve_bwd"] = np.stack(bwd_rows) if bwd_rows else np.full((1, W), -1, np.int32)
-    k["k_solve_bwd_adr"] = np.asarray(bwd_adr, np.int32)     # entry i: first row of level dmax-i
-    k["k_solve_bwd_level"] = np.asarray(bwd_level if bwd_level else [-1], np.int32)  # level published before row r, or -1
-
-    # ---- level-parallel solve / factor schedules (entries of ALL dofs of one depth level side by side on the lanes;
-    #      the kernel combines them with LDS float atomics, so a level is one step instead of one per dof / descendant)
-    by_level = [[i for i in range(nv) if ddepth[i] == l] for l in range(dmax + 1)]
-    np2 = max(1, max((len(by_level[l]) * l + LANES - 1) // LANES for l in range(dmax + 1)))
-    W2 = np2 * LANES
-
-    def level_entries(l):
-        out = []
-        for i in by_level[l]:
-            chain = anc[anc_adr[i]:anc_adr[i + 1]][::-1]          # self, parent, ..., root
-            for p in range(1, l + 1):
-                out.append((Madr[i] + p) | (i << 12) | (int(chain[p]) << 20))
-        return out
-
-    if nM >= 4095:
-        raise ValueError("nM above the 12-bit address field of the solve tables")
-    sol = np.full((max(1, dmax), W2), -1, np.int32)
-    for l in range(1, dmax + 1):
-        ent = level_entries(l)
-        sol[l - 1, :len(ent)] = ent
-    PF = 4                                                     # rows the kernel keeps in flight (RR_PF)
-    seq = np.concatenate([sol[::-1], sol], axis=0)              # backward pass rows (deep -> shallow), then forward rows
-    pad = (-seq.shape[0]) % PF + PF
-    k["k_solve_seq"] = np.concatenate([seq, np.full((pad, W2), -1, np.int32)], axis=0)
-    # ---- atomic-free solve schedule (LDS float atomics cost ~10x a plain read-modify-write on gfx950):
-    #  backward pass (L^-T), level l = dmax..1: GATHER rows -- lane j (an ancestor) adds up L_ij x_i over the dofs i of
-    #  depth l below it (one row per contributor rank), then does ONE plain x_j -= acc;
-    #  forward pass (L^-1), level l = 1..dmax: entry-parallel products L_ij x_j, summed per dof by a DPP wave reduction
-    #  (entries of dof rank r carry r in bits 28..31; an empty slot is exactly -1), written by one lane.
     Wd = NVS * LANES
-    brow, blev = [], []          # rows [Wd] of (L idx | i << 12), -1 = none ; level boundary flags
-    for l in range(dmax, 0, -1):
-        contrib = [[] for _ in range(nv)]
-        for i in by_level[l]:
-            chain = anc[anc_adr[i]:anc_adr[i + 1]][::-1]
-            for pp in range(1, l + 1):
-                contrib[int(chain[pp])].append((Madr[i] + pp) | (i << 12))
-        T = max(len(c) for c in contrib)
-        for t in range(T):
-            row = np.full(Wd, -1, np.int32)
-            for j in range(nv):
-                if t < len(contrib[j]):
-                    row[j] = contrib[j][t]
-            brow.append(row)
-            blev.append(1 if t == T - 1 else 0)      # last row of the level: apply and hand off
-    frow, fmeta = [], []
-    for l in range(1, dmax + 1):
-        if len(by_level[l]) > 15:
-            raise ValueError("more than 15 dofs on one depth level (4-bit rank field)")
-        ent = []
-        for r, i in enumerate(by_level[l]):
-            chain = anc[anc_adr[i]:anc_adr[i + 1]][::-1]
-            for pp in range(1, l + 1):
-                v = (int(Madr[i]) + pp) | (int(i) << 12) | (int(chain[pp]) << 20) | (r << 28)
-                ent.append(v - (1 << 32) if v >= (1 << 31) else v)     # as a signed 32-bit pattern
-        row = np.full(W2, -1, np.int32)
-        row[:len(ent)] = ent
-        frow.append(row)
-        fmeta.append([len(by_level[l])] + [int(x) for x in by_level[l]] + [0] * (15 - len(by_level[l])))
-    padrow = np.full(Wd, -1, np.int32)
-    k["k_solveb"] = np.stack(brow + [padrow] * PF).astype(np.int32)
-    k["k_solveb_last"] = np.asarray(blev + [0] * PF, np.int32)
-    k["k_solveb_rows"] = np.int32(len(brow))
-    k["k_solvef"] = np.stack(frow + [np.full(W2, -1, np.int32)] * PF).astype(np.int32)
-    k["k_solvef_meta"] = np.asarray(fmeta + [[0] * 16] * PF, np.int32)      # [dmax + PF][16]: n_l, dof ids by rank
-    k["k_solve2"] = sol                                        # row l-1: entries (e | i<<12 | j<<20) with depth(i) = l
-    frows, flevel = [], []
-    for l in range(dmax, 0, -1):
-        upd = []
-        for kk in by_level[l]:
-            chain = anc[anc_adr[kk]:anc_adr[kk + 1]][::-1]
-            for q in range(1, l + 1):
-                for p in range(1, q + 1):
-                    dst = Madr[int(chain[p])] + (q - p)
-                    upd.append(((Madr[kk] + p) | ((Madr[kk] + q) << 12), dst | (Madr[kk] << 12)))
-        for r0 in range(0, len(upd), LANES):
-            row = np.full((LANES, 2), -1, np.int32)
-            blk = upd[r0:r0 + LANES]
-            row[:len(blk)] = blk
-            frows.append(row)
-            flevel.append(1 if r0 == 0 else 0)
-    while len(frows) % PF or not frows:                          # pad to a multiple of the prefetch ring
-        frows.append(np.full((LANES, 2), -1, np.int32)); flevel.append(0)
-    frows += [np.full((LANES, 2), -1, np.int32)] * PF; flevel += [0] * PF   # slack rows the ring may prefetch
-    k["k_factor2"] = np.stack(frows).astype(np.int32)            # [R + PF][64][2]
-    k["k_factor2_first"] = np.asarray(flevel, np.int32)          # row opens a new level
-    k["k_factor2_rows"] = np.int32(len(frows) - PF)
+    by_level = [[i for i in range(nv) if ddepth[i] == l] for l in range(dmax + 1)]
+    if nM >= 4095:
+        raise ValueError("nM above the 12-bit address field of the solve job tables")
 
     # ---- atomic-free factorisation and inversion schedules.  Both are lists of LEVELS; a level is a list of table rows
     # of 64 independent operations dst -= src_a * src_b [/ piv] on the sparse-matrix array whose sources are never written
-    # inside the level, so the kernel issues the LDS reads of RR_PF rows (one block) together.  Levels are padded to whole
+    # inside the level, so the kernel issues the LDS reads of RR_BLK rows (one block) together.  Levels are padded to whole
     # blocks.  Operation = 2 ints:  x = a | b << 16,  y = d | q << 16 | flags << 24  (element indices; piv = a + 1 - q).
     # The array has three extra cells: ZERO = nM (0.0), ONE = nM + 1 (1.0), TRASH = nM + 2; an empty operation is
     # a = b = ZERO, q = 0 (piv = ONE), d = TRASH, so the kernel needs no predicates.  flags: 1 = apply the lane's accumulated
@@ -385,15 +217,6 @@ def build_kernel_tables(m):
                     ops.append((mk, int(Madr[kk] + l - da), int(Madr[i] + ddepth[i] - da), 0))
         levels.append([(ops[r0:r0 + LANES], 1) for r0 in range(0, len(ops), LANES)])
     k["k_linv"], k["k_linv_rows"] = pack_levels(levels)
-    # ancestor dof ids of every dof, nearest first, 4 per int: [9][NVS * 64]
-    if dmax > 36:
-        raise ValueError("dof depth above 36")
-    dch = np.zeros((9, Wd), np.int64)
-    for i in range(nv):
-        chain = anc[anc_adr[i]:anc_adr[i + 1]][::-1]
-        for pp in range(1, len(chain)):
-            dch[(pp - 1) >> 2, i] |= int(chain[pp]) << (8 * ((pp - 1) & 3))
-    k["k_dof_chain"] = (dch & 0xFFFFFFFF).astype(np.uint32).view(np.int32).reshape(9, Wd)
     k["k_dof_base"] = (Madr[:nv] + ddepth[:nv]).astype(np.int32)   # entry (i, j) of a descendant i sits at base[i] - depth[j]
 
     # ---- balanced jobs of the two sparse products of the solve (Wave::ldl_solve).  Column product (U' b): column j sums
@@ -463,8 +286,7 @@ def build_kernel_tables(m):
         m["con_solref"].reshape(ncon, 2), m["con_solimp"].reshape(ncon, 5), np.zeros((ncon, 1))], axis=1)  # 26 floats
     # chain of ancestor dofs per contact, [p][lane], leaf first so shallow chains end early
     maxc = int(nanc.max()) if ncon else 1
-    chain_tab = np.full(((max(1, maxc) + UNROLL - 1) // UNROLL * UNROLL, WC), -1, np.int32)
-    rows = [[] for _ in range(nv)]                     # J^T f gather lists per dof
+    chain_tab = np.full((max(1, maxc), WC), -1, np.int32)
     for c in range(ncon):
         d = int(lastdof[c])
         if d < 0:
@@ -472,8 +294,6 @@ def build_kernel_tables(m):
         chain = anc[anc_adr[d]:anc_adr[d + 1]][::-1]   # leaf..root
         for p, dd in enumerate(chain):
             chain_tab[p, c] = int(dd)
-            rows[int(dd)].append(c | ((m["con_jadr"][c] + 3 * p) << 8))
-    k["k_con_chain"] = chain_tab
     if maxc > 36:
         raise ValueError("contact ancestor chains longer than 36 dofs are not supported by the kernel")
     packed = np.zeros((9, WC), np.int64)
@@ -481,14 +301,4 @@ def build_kernel_tables(m):
         for p in range(int(nanc[c])):
             packed[p // 4, c] |= int(chain_tab[p, c]) << (8 * (p % 4))
     k["k_con_chain_packed"] = packed.astype(np.uint32).view(np.int32)
-    # byte table of all chains back to back (contact c starts at byte coff[c], k_con_i[:,5]); padded, stored as int32 words
-    coff, blob = [], []
-    for c in range(ncon):
-        coff.append(len(blob))
-        d = int(lastdof[c])
-        blob += [int(x) for x in (anc[anc_adr[d]:anc_adr[d + 1]][::-1] if d >= 0 else [])]
-    blob += [0] * (8 - len(blob) % 4)
-    k["k_con_chain_bytes"] = np.frombuffer(bytes(blob), dtype=np.int32).copy()
-
-    k["k_jtf"] = lane_table(rows)
     return k

@@ -31,19 +31,26 @@ def model_and_state(request, oracle_built):
     return m, M, d
 
 
-def test_mulm_table(model_and_state):
+def test_mulm_by_solve_jobs(model_and_state):
+    """numpy restatement of Wave::mul_m: y = M x from the balanced column / row jobs of the solve, on qM."""
     m, M, d = model_and_state
     nv = M.nv
     qM = d.get("qM")
     Md = dense_from_sparse(m, qM)
     x = np.random.default_rng(1).normal(size=nv)
-    tab = m["k_mulm"]
-    y = np.zeros(tab.shape[1])
-    for t in range(tab.shape[0]):
-        e = tab[t]
-        ok = e >= 0
-        y[ok] += qM[e[ok] >> 8] * x[e[ok] & 255]
-    np.testing.assert_allclose(y[:nv], Md @ x, rtol=1e-12, atol=1e-14)
+    base, Madr = m["k_dof_base"], m["k_dof_i"][:, 4]
+    cj, rj, rch, own = m["k_coljob"].view(np.uint32), m["k_rowjob"], m["k_rowjob_chain"].view(np.uint32), m["k_jobown"].view(np.uint32)
+    pc, pr = np.zeros(len(cj)), np.zeros(len(rj))
+    for t, e in enumerate(cj):
+        j, i0, n, dj = int(e & 255), int((e >> 8) & 255), int((e >> 16) & 255), int(e >> 24)
+        assert n == 0 or dj == m["k_dof_i"][j, 3]
+        pc[t] = sum(qM[base[i] - dj] * x[i] for i in range(i0, i0 + n))
+    for t, e in enumerate(rj):
+        adr0, n = int(e & 4095), int(e >> 12)
+        pr[t] = sum(qM[adr0 + u] * x[(int(rch[u >> 2, t]) >> (8 * (u & 3))) & 255] for u in range(n))
+    y = np.array([qM[Madr[i]] * x[i] + pc[int(own[i] & 255):int(own[i] & 255) + int((own[i] >> 8) & 255)].sum() +
+                  pr[int((own[i] >> 16) & 255):int((own[i] >> 16) & 255) + int(own[i] >> 24)].sum() for i in range(nv)])
+    np.testing.assert_allclose(y, Md @ x, rtol=1e-12, atol=1e-14)
 
 
 PF = 2          # rows per block of the level schedules (RR_BLK)
@@ -157,101 +164,20 @@ def test_factor_and_solve_tables(model_and_state):
     np.testing.assert_allclose(Md @ x, b, rtol=1e-7, atol=1e-9)
 
 
-def test_jtf_and_chain_tables(model_and_state):
+def test_contact_chain_is_a_dfs_interval(model_and_state):
+    """Wave::update_constraint applies a contact's force to dof d iff d <= leaf <= last_desc(d) (leaf = first byte of the
+    packed chain): that set must be exactly the ancestor chain of the contact's body, which jac_mul walks byte by byte."""
     m, M, d = model_and_state
     nv, ncon = M.nv, M.ncon
-    chain = m["k_con_chain"]
-    jadr = m["con_jadr"]
-    # a random "J" in the kernel's layout and random base forces: J^T f by gather lists == by chains
-    rng = np.random.default_rng(3)
-    J = rng.normal(size=jadr[-1])
-    f = rng.normal(size=(ncon, 3))
-    want = np.zeros(nv)
+    last = m["k_dof_i"][:, 10]
+    packed = m["k_con_chain_packed"].view(np.uint32)
+    anc_adr, anc = m["dof_ancadr"], m["dof_anc"]
     for c in range(ncon):
-        nanc = m["k_con_i"][c, 4]
-        for p in range(nanc):
-            dd = chain[p, c]
-            assert dd >= 0
-            want[dd] += J[jadr[c] + 3 * p:jadr[c] + 3 * p + 3] @ f[c]
-        assert nanc == chain.shape[0] or chain[nanc, c] == -1
-    tab = m["k_jtf"]
-    got = np.zeros(tab.shape[1])
-    for t in range(tab.shape[0]):
-        e = tab[t]
-        ok = np.nonzero(e >= 0)[0]
-        c, a = e[ok] & 255, e[ok] >> 8
-        got[ok] += J[a] * f[c, 0] + J[a + 1] * f[c, 1] + J[a + 2] * f[c, 2]
-    np.testing.assert_allclose(got[:nv], want, rtol=1e-12, atol=1e-13)
-
-
-def test_level_tables(model_and_state):
-    m, M, d = model_and_state
-    adr, order = m["k_lvl_adr"], m["k_lvl_body"]
-    seen = set()
-    for L in range(1, len(adr) - 1):
-        bodies = order[adr[L]:adr[L + 1]]
-        assert 0 < len(bodies) <= LANES
-        for b in bodies:
-            assert m["body_depth"][b] == L
-            assert m["body_parentid"][b] == 0 or m["body_parentid"][b] in seen
-        seen.update(int(b) for b in bodies)
-    assert seen == set(range(1, M.nbody))
-
-
-def kernel_factor2(m, qM):
-    """numpy restatement of the level-parallel Wave::factor (k_factor2 rows, atomics = np.add.at)."""
-    L = qM.copy()
-    tab, first = m["k_factor2"], m["k_factor2_first"]
-    for r in range(tab.shape[0]):
-        e = tab[r]
-        ok = e[:, 0] >= 0
-        a, bq = e[ok, 0] & 4095, e[ok, 0] >> 12
-        dst, piv = e[ok, 1] & 4095, e[ok, 1] >> 12
-        np.add.at(L, dst, -(L[bq] * (L[a] / L[piv])))
-    Madr = m["k_dof_i"][:, 4]
-    dinv = 1.0 / L[Madr]
-    for e_, ij in enumerate(m["k_M_ij"]):
-        i, j = ij & 0xFFFF, ij >> 16
-        if i != j:
-            L[e_] *= dinv[i]
-    return L, dinv
-
-
-def kernel_solve2(m, L, dinv, x):
-    """numpy restatement of the level-parallel Wave::ldl_solve (k_solve2 rows)."""
-    nv = int(m["nv"])
-    tab = m["k_solve2"]
-    sx = x.copy()
-    for l in range(tab.shape[0] - 1, -1, -1):
-        e = tab[l][tab[l] >= 0]
-        np.add.at(sx, e >> 20, -(L[e & 4095] * sx[(e >> 12) & 255]))
-    sx *= dinv
-    for l in range(tab.shape[0]):
-        e = tab[l][tab[l] >= 0]
-        np.add.at(sx, (e >> 12) & 255, -(L[e & 4095] * sx[e >> 20]))
-    return sx
-
-
-def test_level_parallel_factor_and_solve_tables(model_and_state):
-    m, M, d = model_and_state
-    qM, qLD = d.get("qM"), d.get("qLD")
-    L, dinv = kernel_factor2(m, qM)
-    np.testing.assert_allclose(L, qLD, rtol=1e-9, atol=1e-16)
-    np.testing.assert_allclose(dinv, d.get("qLDiagInv"), rtol=1e-9)
-    Md = dense_from_sparse(m, qM)
-    b = np.random.default_rng(4).normal(size=M.nv)
-    x = kernel_solve2(m, L, dinv, b)
-    np.testing.assert_allclose(Md @ x, b, rtol=1e-7, atol=1e-9)
-    # a level's rows never read an entry that the same level writes (reads: rows of that level; writes: ancestor rows)
-    tab, first = m["k_factor2"], m["k_factor2_first"]
-    r = 0
-    while r < tab.shape[0]:
-        r1 = r + 1
-        while r1 < tab.shape[0] and not first[r1]:
-            r1 += 1
-        e = tab[r:r1].reshape(-1, 2)
-        e = e[e[:, 0] >= 0]
-        reads = set((e[:, 0] & 4095).tolist()) | set((e[:, 0] >> 12).tolist()) | set((e[:, 1] >> 12).tolist())
-        writes = set((e[:, 1] & 4095).tolist())
-        assert not (reads & writes)
-        r = r1
+        nanc = int(m["k_con_i"][c, 4])
+        chain = [(int(packed[p >> 2, c]) >> (8 * (p & 3))) & 255 for p in range(nanc)]
+        leaf = int(m["k_con_i"][c, 3])
+        if leaf < 0:
+            assert nanc == 0
+            continue
+        assert chain[0] == leaf and chain == [int(x) for x in anc[anc_adr[leaf]:anc_adr[leaf + 1]][::-1]]
+        assert sorted(chain) == [dd for dd in range(nv) if dd <= leaf <= last[dd]]
