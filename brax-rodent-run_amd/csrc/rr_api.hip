@@ -42,17 +42,11 @@ struct rr_model {
 static void layout(rr_model* m) {
   RRDims& k = m->kd;
   const rr_dims& d = m->dims;
-  int o = 0;
-  auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
-  k.o_qpos = take(d.nq); k.o_qvel = take(d.nv); k.o_act = take(d.nu); k.o_ctrl = take(d.nu);
-  // pose cells (xpos | xquat) are recycled as the 6*nv scratch of the mass-matrix build
-  { const int pose = std::max(7 * d.nbody + 4, 6 * d.nv); k.o_xpos = take(pose); k.o_xquat = k.o_xpos + ((3 * d.nbody + 3) & ~3); }
-  k.o_cinert = take(10 * d.nbody);   // composite inertia accumulates in place
-  k.o_cdof = take(6 * d.nv); k.o_cvel = take(6 * d.nbody);
-  k.o_qM = take(d.nM);
-  k.o_qLD = take(std::max(std::max(d.nM + 3, 12 * d.nbody), 2 * d.nv));   // also cacc | cfrc and the sin/cos scratch
-  k.o_vec = take(d.nv); k.o_x = take(d.nv); k.o_arm = take(2 * d.nv); k.o_warm = take(d.nv); k.o_qact = take(d.nv); k.o_base = take(d.nv);
-  k.lds_floats = o;
+  const RRLayout L = rr_layout(d.nq, d.nv, d.nu, d.nbody, d.nM);
+  k.o_qpos = L.o_qpos; k.o_qvel = L.o_qvel; k.o_act = L.o_act; k.o_ctrl = L.o_ctrl; k.o_xpos = L.o_xpos; k.o_xquat = L.o_xquat;
+  k.o_cinert = L.o_cinert; k.o_cdof = L.o_cdof; k.o_cvel = L.o_cvel; k.o_qM = L.o_qM; k.o_qLD = L.o_qLD; k.o_vec = L.o_vec; k.o_x = L.o_x;
+  k.o_arm = L.o_arm; k.o_warm = L.o_warm; k.o_qact = L.o_qact; k.o_base = L.o_base; k.lds_floats = L.lds_floats;
+  const int o = L.lds_floats;
   // staging of the line search's compacted rows: cinert | cvel | pose regions each hold 4*ncon + nv floats
   m->stage_ok = 4 * d.ncon + d.nv <= std::min(std::min(10 * d.nbody, 6 * d.nbody), std::max(7 * d.nbody + 4, 6 * d.nv));
   // debug dump
@@ -208,17 +202,19 @@ static int upload_levels(rr_batch* b, const char* name, rr_gi* dst) {
 }
 
 typedef void (*kern_t)(const RRDims, const RRTables, const RRIO, const int, const int);
-static kern_t pick_kernel(int nbs, int nvs, int ncs, bool prof = false) {
-  if (prof) return (nbs == 2 && nvs == 2 && ncs == 1) ? rr_step_kernel<2, 2, 1, true> : nullptr;
-  if (nbs == 1 && nvs == 1 && ncs == 1) return rr_step_kernel<1, 1, 1, false>;
-  if (nbs == 2 && nvs == 2 && ncs == 1) return rr_step_kernel<2, 2, 1, false>;
-  if (nbs == 3 && nvs == 3 && ncs == 2) return rr_step_kernel<3, 3, 2, false>;
+static kern_t pick_kernel(const rr_model* m, bool prof = false) {
+  const int nbs = m->NBS, nvs = m->NVS, ncs = m->NCS;
+  if (prof) return (nbs == 2 && nvs == 2 && ncs == 1) ? rr_step_kernel<2, 2, 1, true, RRDims> : nullptr;
+  if (nbs == 2 && nvs == 2 && ncs == 1 && RRDimsRodent::matches(m->kd)) return rr_step_kernel<2, 2, 1, false, RRDimsRodent>;   // fixed-dimension instance
+  if (nbs == 1 && nvs == 1 && ncs == 1) return rr_step_kernel<1, 1, 1, false, RRDims>;
+  if (nbs == 2 && nvs == 2 && ncs == 1) return rr_step_kernel<2, 2, 1, false, RRDims>;
+  if (nbs == 3 && nvs == 3 && ncs == 2) return rr_step_kernel<3, 3, 2, false, RRDims>;
   return nullptr;
 }
 
 extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t device, void* stream, rr_batch** out) {
   if (!m || !out || num_envs <= 0) return fail(RR_EINVAL, "rr_batch_create: bad argument");
-  if (!pick_kernel(m->NBS, m->NVS, m->NCS)) return fail(RR_EUNSUPPORTED, "rr_batch_create: no kernel instance for this model's slot counts");
+  if (!pick_kernel(m)) return fail(RR_EUNSUPPORTED, "rr_batch_create: no kernel instance for this model's slot counts");
   HIPCHK(hipSetDevice(device));
   rr_batch* b = new rr_batch();
   b->m = m; b->N = num_envs; b->device = device; b->stream = (hipStream_t)stream; b->kd = m->kd;
@@ -230,7 +226,7 @@ extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t devi
   UP(act_f, "k_act_f") UP(con_f, "k_con_f") UP(root_mass, "k_root_mass")
 #undef UP
   if ((rc = upload_levels(b, "k_factor3", &b->T.factor3)) || (rc = upload_levels(b, "k_linv", &b->T.linv))) { rr_batch_destroy(b); return rc; }
-  kern_t kern = pick_kernel(m->NBS, m->NVS, m->NCS);
+  kern_t kern = pick_kernel(m);
   if (!m->stage_ok) { rr_batch_destroy(b); return fail(RR_EUNSUPPORTED, "rr_batch_create: 4*ncon + nv exceeds the line-search staging cells (6*nbody)"); }
   if (m->dims.lds_bytes > 64 * 1024) { rr_batch_destroy(b); return fail(RR_EUNSUPPORTED, "rr_batch_create: per-env working set exceeds 160 KiB LDS"); }
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, m->dims.lds_bytes);
@@ -279,7 +275,7 @@ static int launch(rr_batch* b, const rr_state* st, const float* ctrl, int n_fram
   }
   io.mode = mode;
   HIPCHK(hipSetDevice(b->device));
-  kern_t kern = pick_kernel(b->m->NBS, b->m->NVS, b->m->NCS, b->prof != nullptr);
+  kern_t kern = pick_kernel(b->m, b->prof != nullptr);
   if (!kern) return fail(RR_EUNSUPPORTED, "launch: no diagnostic kernel instance for this model");
   io.prof = b->prof;
   RRDims kd = b->kd;
@@ -356,7 +352,7 @@ extern "C" int rr_debug_layout(const rr_batch* b, const char*** names, const int
 extern "C" int rr_batch_set_profile(rr_batch* b, uint64_t* dev_cycles) {
   if (!b) return fail(RR_EINVAL, "rr_batch_set_profile: null batch");
   if (dev_cycles) {
-    kern_t kern = pick_kernel(b->m->NBS, b->m->NVS, b->m->NCS, true);
+    kern_t kern = pick_kernel(b->m, true);
     if (!kern) return fail(RR_EUNSUPPORTED, "rr_batch_set_profile: no diagnostic kernel instance for this model");
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, b->m->dims.lds_bytes);
     if (e != hipSuccess) return fail(RR_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));

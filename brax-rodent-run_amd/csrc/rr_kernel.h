@@ -39,6 +39,59 @@ struct RRDims {
       g_qfrc_constraint, g_misc, dbg_floats;
 };
 
+// LDS layout of one environment (float offsets).  One constexpr function serves the host (rr_api.hip layout) and the
+// kernel instance compiled for fixed model dimensions.
+struct RRLayout {
+  int o_qpos, o_qvel, o_act, o_ctrl, o_xpos, o_xquat, o_cinert, o_cdof, o_cvel, o_qM, o_qLD, o_vec, o_x, o_arm, o_warm, o_qact, o_base, lds_floats;
+};
+constexpr int rr_imax(int a, int b) { return a > b ? a : b; }
+constexpr int rr_up4(int n) { return (n + 3) & ~3; }
+constexpr RRLayout rr_layout(int nq, int nv, int nu, int nbody, int nM) {
+  RRLayout k{};
+  int o = 0;
+  k.o_qpos = o; o += rr_up4(nq);
+  k.o_qvel = o; o += rr_up4(nv);
+  k.o_act = o; o += rr_up4(nu);
+  k.o_ctrl = o; o += rr_up4(nu);
+  // pose cells (xpos | xquat) are recycled as the 6*nv scratch of the mass-matrix build and as solver staging
+  k.o_xpos = o; o += rr_up4(rr_imax(7 * nbody + 4, 6 * nv));
+  k.o_xquat = k.o_xpos + rr_up4(3 * nbody);
+  k.o_cinert = o; o += rr_up4(10 * nbody);      // composite inertia accumulates in place
+  k.o_cdof = o; o += rr_up4(6 * nv);
+  k.o_cvel = o; o += rr_up4(6 * nbody);
+  k.o_qM = o; o += rr_up4(nM);
+  k.o_qLD = o; o += rr_up4(rr_imax(rr_imax(nM + 3, 12 * nbody), 2 * nv));   // also cacc | cfrc and the sin/cos scratch
+  k.o_vec = o; o += rr_up4(nv);
+  k.o_x = o; o += rr_up4(nv);
+  k.o_arm = o; o += rr_up4(2 * nv);
+  k.o_warm = o; o += rr_up4(nv);
+  k.o_qact = o; o += rr_up4(nv);
+  k.o_base = o; o += rr_up4(nv);
+  k.lds_floats = o;
+  return k;
+}
+
+// Dimensions of the benchmark model family (rodent_optimized.xml) as compile-time constants: the instance built on them
+// has its loop bounds, bounds checks and LDS addresses as immediates instead of ~40 scalar registers (the generic instance
+// spills hundreds of SGPRs to VGPR lanes).  Members of the same name hide the run-time fields of RRDims; everything else
+// (solver options, table row counts, debug offsets) stays run-time.  The host selects it only when every constant matches.
+struct RRDimsRodent : RRDims {
+  static constexpr int nq = 74, nv = 73, nu = 30, nbody = 66, njnt = 68, nM = 1119, ncon = 59, dmax = 35, nroot = 1, obs_dim = 1263, nround = 6;
+  static constexpr RRLayout LY = rr_layout(nq, nv, nu, nbody, nM);
+  static constexpr int o_qpos = LY.o_qpos, o_qvel = LY.o_qvel, o_act = LY.o_act, o_ctrl = LY.o_ctrl, o_xpos = LY.o_xpos, o_xquat = LY.o_xquat,
+                       o_cinert = LY.o_cinert, o_cdof = LY.o_cdof, o_cvel = LY.o_cvel, o_qM = LY.o_qM, o_qLD = LY.o_qLD, o_vec = LY.o_vec,
+                       o_x = LY.o_x, o_arm = LY.o_arm, o_warm = LY.o_warm, o_qact = LY.o_qact, o_base = LY.o_base, lds_floats = LY.lds_floats;
+  __host__ __device__ RRDimsRodent(const RRDims& d) : RRDims(d) {}
+  static bool matches(const RRDims& d) {
+    const RRDims& r = d;
+    return r.nq == nq && r.nv == nv && r.nu == nu && r.nbody == nbody && r.njnt == njnt && r.nM == nM && r.ncon == ncon && r.dmax == dmax &&
+           r.nroot == nroot && r.obs_dim == obs_dim && r.nround == nround && r.o_qpos == o_qpos && r.o_qvel == o_qvel && r.o_act == o_act &&
+           r.o_ctrl == o_ctrl && r.o_xpos == o_xpos && r.o_xquat == o_xquat && r.o_cinert == o_cinert && r.o_cdof == o_cdof &&
+           r.o_cvel == o_cvel && r.o_qM == o_qM && r.o_qLD == o_qLD && r.o_vec == o_vec && r.o_x == o_x && r.o_arm == o_arm &&
+           r.o_warm == o_warm && r.o_qact == o_qact && r.o_base == o_base && r.lds_floats == lds_floats;
+  }
+};
+
 // Table pointers carry the global address space in their type, so every table access is a global_load (never flat).
 typedef const int __attribute__((address_space(1)))* rr_gi;
 typedef const float __attribute__((address_space(1)))* rr_gf;
@@ -246,9 +299,9 @@ __device__ __forceinline__ BodyC load_bodyc(const RRTables& T, int b, int nbody)
 #ifndef RR_REP_KIN
 #define RR_REP_KIN 0
 #endif
-template <int NBS, int NVS, int NCS>
+template <int NBS, int NVS, int NCS, class DT>
 struct Wave {
-  const RRDims& D;
+  const DT& D;
   const RRTables& T;
   const int lane;
   float* const lds;
@@ -290,7 +343,7 @@ struct Wave {
     if (PROF) { const unsigned long long t = __builtin_readcyclecounter(); pt[i] += t - pt_last; pt_last = t; }
   }
 
-  __device__ Wave(const RRDims& d, const RRTables& t, float* l)
+  __device__ Wave(const DT& d, const RRTables& t, float* l)
       : D(d), T(t), lane(threadIdx.x), lds(l) {
     s_qpos = l + d.o_qpos; s_qvel = l + d.o_qvel; s_act = l + d.o_act; s_ctrl = l + d.o_ctrl;
     s_xpos = l + d.o_xpos; s_xquat = l + d.o_xquat; s_cinert = l + d.o_cinert; s_crb = s_cinert;
@@ -1408,15 +1461,16 @@ struct Wave {
 };
 
 // ------------------------------------------------------------------------------------------ kernel
-template <int NBS, int NVS, int NCS, bool PROF>
-__global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(const RRDims D, const RRTables T, const RRIO io, const int num_envs,
+template <int NBS, int NVS, int NCS, bool PROF, class DT>
+__global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(const RRDims Dk, const RRTables T, const RRIO io, const int num_envs,
                                                            const int n_frames) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int env = blockIdx.x;
   if (env >= num_envs) return;
   // the level schedules address LDS by absolute byte address: the dynamic segment must start at 0 (no static LDS here)
   if ((unsigned)(size_t)(float __attribute__((address_space(3)))*)lds != 0u) __builtin_trap();
-  Wave<NBS, NVS, NCS> w(D, T, lds);
+  const DT D(Dk);
+  Wave<NBS, NVS, NCS, DT> w(D, T, lds);
   const int lane = threadIdx.x;
   float* dbg = io.dbg ? io.dbg + (size_t)env * D.dbg_floats : nullptr;
 
@@ -1527,7 +1581,7 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
     {   // sparse-matrix entry ids and contact chains: needed from here to the end of the substep
       const int ol = opaque(lane);
 #pragma unroll
-      for (int it = 0; it < Wave<NBS, NVS, NCS>::NME; ++it) {
+      for (int it = 0; it < Wave<NBS, NVS, NCS, DT>::NME; ++it) {
         const int e = ol + RR_LANES * it;
         w.ment[it] = e < D.nM ? T.M_ij_k[e] : -1;
       }
