@@ -204,7 +204,7 @@ static int upload_levels(rr_batch* b, const char* name, rr_gi* dst) {
 typedef void (*kern_t)(const RRDims, const RRTables, const RRIO, const int, const int);
 static kern_t pick_kernel(const rr_model* m, bool prof = false) {
   const int nbs = m->NBS, nvs = m->NVS, ncs = m->NCS;
-  if (prof) return (nbs == 2 && nvs == 2 && ncs == 1) ? rr_step_kernel<2, 2, 1, true, RRDims> : nullptr;
+  if (prof) return (nbs == 2 && nvs == 2 && ncs == 1) ? (RRDimsRodent::matches(m->kd) ? rr_step_kernel<2, 2, 1, true, RRDimsRodent> : rr_step_kernel<2, 2, 1, true, RRDims>) : nullptr;
   if (nbs == 2 && nvs == 2 && ncs == 1 && RRDimsRodent::matches(m->kd)) return rr_step_kernel<2, 2, 1, false, RRDimsRodent>;   // fixed-dimension instance
   if (nbs == 1 && nvs == 1 && ncs == 1) return rr_step_kernel<1, 1, 1, false, RRDims>;
   if (nbs == 2 && nvs == 2 && ncs == 1) return rr_step_kernel<2, 2, 1, false, RRDims>;

@@ -1461,8 +1461,22 @@ struct Wave {
 };
 
 // ------------------------------------------------------------------------------------------ kernel
+// The kernel's explicit arguments as they lie in the kernarg segment.  The ~20 pointers of RRIO are needed only before the
+// first and after the last substep; read through the (opaque) kernarg pointer where they are used, they do not occupy
+// scalar registers -- or their spill lanes -- during the substeps.
+struct RRKArgs { RRDims D; RRTables T; RRIO io; int num_envs, n_frames; };
+static __device__ __forceinline__ RRIO load_io() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const char __attribute__((address_space(4)))* p = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return *(const RRIO __attribute__((address_space(4)))*)(p + offsetof(RRKArgs, io));
+#else
+  return RRIO{};
+#endif
+}
+
 template <int NBS, int NVS, int NCS, bool PROF, class DT>
-__global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(const RRDims Dk, const RRTables T, const RRIO io, const int num_envs,
+__global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(const RRDims Dk, const RRTables T, const RRIO io_kernarg, const int num_envs,
                                                            const int n_frames) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int env = blockIdx.x;
@@ -1472,6 +1486,8 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
   const DT D(Dk);
   Wave<NBS, NVS, NCS, DT> w(D, T, lds);
   const int lane = threadIdx.x;
+  RRIO io = load_io();
+  const int mode = io.mode;
   float* dbg = io.dbg ? io.dbg + (size_t)env * D.dbg_floats : nullptr;
 
   // ---- load state
@@ -1499,11 +1515,12 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
   w.sync();
 
   if (PROF) { for (int i = 0; i < RR_NPH; ++i) w.pt[i] = 0; w.pt_last = __builtin_readcyclecounter(); }
-  const int frames = (io.mode & 1) ? n_frames : 1;
+  const int frames = (mode & 1) ? n_frames : 1;
   int niter = 0;
   float xq1[4] = {1, 0, 0, 0};   // xquat of body 1 at the last forward pass (obs: xmat[1])
   for (int f = 0; f < frames; ++f) {
     const bool last = f == frames - 1;
+    if (last) io = load_io();
     float* dg = last ? dbg : nullptr;
     float bias[NVS], passive[NVS];
     w.template stamp<PROF>(15);
@@ -1628,11 +1645,12 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
       }
       if (lane == 0) { dg[D.g_misc] = (float)niter; dg[D.g_misc + 1] = w.cost; }
     }
-    if (io.mode & 1) w.euler();
+    if (mode & 1) w.euler();
     w.template stamp<PROF>(13);
   }
 
   w.template stamp<PROF>(14);
+  io = load_io();
   if (PROF && io.prof && lane == 0) for (int i = 0; i < RR_NPH; ++i) io.prof[(size_t)env * RR_NPH + i] = w.pt[i];
   // ---- write back state
   for (int i = lane; i < D.nq; i += RR_LANES) io.qpos[(size_t)env * D.nq + i] = w.s_qpos[i];
@@ -1649,7 +1667,7 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
 
   // ---- reference env epilogue [REF Rodent_Env_Brax.py:103-158]
   if (io.obs) {
-    const bool is_reset = (io.mode & 2) != 0;
+    const bool is_reset = (mode & 2) != 0;
     const int old_frame = io.cur_frame[env];
     const int new_frame = is_reset ? old_frame : old_frame + 1;
     float* ob = io.obs + (size_t)env * D.obs_dim;
