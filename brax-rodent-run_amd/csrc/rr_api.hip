@@ -186,12 +186,13 @@ static int upload_levels(rr_batch* b, const char* name, rr_gi* dst) {
   const Entry* e = b->m->find(name);
   const uint32_t base = (uint32_t)b->m->kd.o_qLD * 4u;
   std::vector<uint32_t> t((const uint32_t*)e->data, (const uint32_t*)e->data + e->count);
-  for (size_t i = 0; i + 1 < t.size(); i += 2) {
-    const uint32_t x = t[i], y = t[i + 1];
-    const uint32_t a = (x & 0xFFFFu) * 4u + base, bq = (x >> 16) * 4u + base, d = (y & 0xFFFFu) * 4u + base, q = ((y >> 16) & 0xFFu) * 4u;
-    if (a > 0xFFFFu || bq > 0xFFFFu || d > 0xFFFFu || q > 0xFFu) return fail(RR_EUNSUPPORTED, "level schedule does not fit the 16-bit LDS address fields");
-    t[i] = a | (bq << 16);
-    t[i + 1] = d | (q << 16) | (y & 0xFF000000u);
+  for (size_t i = 0; i + 3 < t.size(); i += 4) {        // x = a | b0 << 16, y = d0 | d1 << 16, z = d2 | d3 << 16, w = q | flags << 8
+    uint32_t f[6] = {t[i] & 0xFFFFu, t[i] >> 16, t[i + 1] & 0xFFFFu, t[i + 1] >> 16, t[i + 2] & 0xFFFFu, t[i + 2] >> 16};
+    for (uint32_t& v : f) { v = v * 4u + base; if (v > 0xFFFFu) return fail(RR_EUNSUPPORTED, "level schedule does not fit the 16-bit LDS address fields"); }
+    const uint32_t q = (t[i + 3] & 0xFFu) * 4u;
+    if (q > 0xFFu) return fail(RR_EUNSUPPORTED, "level schedule: pivot offset above 8 bits");
+    t[i] = f[0] | (f[1] << 16); t[i + 1] = f[2] | (f[3] << 16); t[i + 2] = f[4] | (f[5] << 16);
+    t[i + 3] = q | (t[i + 3] & 0xFFFFFF00u);
   }
   void* p = nullptr;
   HIPCHK(hipMalloc(&p, t.size() * 4));

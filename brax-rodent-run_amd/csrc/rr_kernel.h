@@ -19,8 +19,7 @@
 #define RR_LANES 64
 #define RR_DOFI 12   // ints per dof in k_dof_i
 #define RR_BODYI 12  // ints per body in k_body_i
-#define RR_BLK 2     // rows per block of the level schedules (ktables BLK): their LDS reads are issued together
-#define RR_RING 8    // rows of a level schedule in flight (ktables RING)
+#define RR_RING 4    // rows of a level schedule in flight (ktables RING)
 #define RR_NPH 16    // phases of the diagnostic (s_memtime) build
 #define RR_MINVAL 1e-15f
 #define RR_MINIMP 0.0001f
@@ -60,7 +59,7 @@ constexpr RRLayout rr_layout(int nq, int nv, int nu, int nbody, int nM) {
   k.o_cdof = o; o += rr_up4(6 * nv);
   k.o_cvel = o; o += rr_up4(6 * nbody);
   k.o_qM = o; o += rr_up4(nM);
-  k.o_qLD = o; o += rr_up4(rr_imax(rr_imax(nM + 3, 12 * nbody), 2 * nv));   // also cacc | cfrc and the sin/cos scratch
+  k.o_qLD = o; o += rr_up4(rr_imax(rr_imax(nM + 4, 12 * nbody), 2 * nv));   // also cacc | cfrc and the sin/cos scratch
   k.o_vec = o; o += rr_up4(nv);
   k.o_x = o; o += rr_up4(nv);
   k.o_arm = o; o += rr_up4(2 * nv);
@@ -723,58 +722,57 @@ struct Wave {
   }
 
   // Executor of the level schedules of the factorisation and the inversion (rodent_amd/ktables.py pack_levels).  A table
-  // row is 64 independent operations dst -= a * b [/ piv] on the sparse-matrix array s_qLD.  A lane accumulates a * b / piv
-  // over consecutive rows and, on a row flagged 1 (bits 24.. of the second word, the same in every lane), stores
-  // dst = dst_old - sum: a plain read-modify-write -- within a level every dst belongs to one lane and is written once,
-  // and no source of a level is written by that level.  The LDS reads of a block of RR_PF rows -- sources and old target
-  // values -- are therefore issued together, one LDS round trip per block instead of two per row; levels end at block
-  // ends (flag 2: one LDS hand-off).  ATOMIC-FREE: an LDS float atomic costs ~10x a plain read-modify-write on gfx950 and
-  // >1000 cycles with every wave of the CU issuing them.  PREDICATE-FREE: the host turns the table's element indices into
-  // LDS byte addresses at upload, and empty operations address the cells ZERO (0.0), ONE (1.0) and TRASH kept behind the
-  // nM entries, so a row costs 3-4 address extractions, 3-4 ds_reads, the arithmetic and one ds_write.
+  // row is 64 independent QUAD operations on the sparse-matrix array s_qLD: four targets d_j -= a * b_j [/ piv], b_j four
+  // consecutive entries (the targets of one source row are consecutive entries of an ancestor row, so one shared operand,
+  // one reciprocal and one run of four feed four multiply-adds).  A lane accumulates over consecutive rows and, on a row
+  // flagged 1 (the flags are the same in every lane), stores d_j = d_j_old - sum_j: plain read-modify-writes -- within a
+  // level every target belongs to one lane and is written once, and no source of a level is written by that level.  The
+  // LDS reads of a row -- sources and old target values -- are therefore issued together, one LDS round trip per row of
+  // up to 256 multiply-adds; a level ends with one LDS hand-off (flag 2).  ATOMIC-FREE: an LDS float atomic costs ~10x a
+  // plain read-modify-write on gfx950 and >1000 cycles with every wave of the CU issuing them.  PREDICATE-FREE: the host
+  // turns the table's element indices into LDS byte addresses at upload, and empty operations / the unused targets of
+  // short runs address the cells ZERO (0.0), ONE (1.0) and TRASH kept behind the nM entries.
   // 1/piv: v_rcp_f32 refined by one Newton step (the row scaling by 1/D after the sweep uses the exact quotient).
-  // Rows are prefetched one block ahead (8-byte global loads).
+  // Rows (16 B per lane) are prefetched RR_RING ahead.
   typedef float __attribute__((address_space(3)))* rr_lf;
   static __device__ __forceinline__ float lds_ld(int byte_adr) { return *(rr_lf)(size_t)(unsigned)byte_adr; }
   static __device__ __forceinline__ void lds_st(int byte_adr, float v) { *(rr_lf)(size_t)(unsigned)byte_adr = v; }
+  typedef int rr_v4i __attribute__((ext_vector_type(4)));
   template <bool DIV>
   __device__ __forceinline__ void run_levels(rr_gi table, int nrows) {
-    typedef const unsigned long long __attribute__((address_space(1)))* rr_gu64;
-    rr_gu64 tab = (rr_gu64)table;
-    int2 ring[RR_RING];        // rows in flight: the L2 latency of the table stream exceeds one block of LDS work
+    typedef const rr_v4i __attribute__((address_space(1)))* rr_gv4;
+    rr_gv4 tab = (rr_gv4)table;
+    rr_v4i ring[RR_RING];
 #pragma unroll
-    for (int u = 0; u < RR_RING; ++u) { const unsigned long long q_ = tab[u * RR_LANES + lane]; ring[u].x = (int)(unsigned)q_; ring[u].y = (int)(q_ >> 32); }
-    float acc = 0.0f;
+    for (int u = 0; u < RR_RING; ++u) ring[u] = tab[u * RR_LANES + lane];
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int r0 = 0; r0 < nrows; r0 += RR_RING) {
 #pragma unroll
-      for (int h = 0; h < RR_RING / RR_BLK; ++h) {
-        int2 e[RR_BLK];
+      for (int u = 0; u < RR_RING; ++u) {
+        const rr_v4i e = ring[u];
+        ring[u] = tab[(r0 + RR_RING + u) * RR_LANES + lane];
+        const int a4 = e.x & 0xFFFF, b4 = (int)((unsigned)e.x >> 16);
+        const int d4[4] = {e.y & 0xFFFF, (int)((unsigned)e.y >> 16), e.z & 0xFFFF, (int)((unsigned)e.z >> 16)};
+        const float va = lds_ld(a4);
+        const float vp = DIV ? lds_ld(a4 - (e.w & 0xFF) + 4) : 1.0f;
+        float vb[4], vo[4];
 #pragma unroll
-        for (int u = 0; u < RR_BLK; ++u) {
-          e[u] = ring[h * RR_BLK + u];
-          const unsigned long long q_ = tab[(r0 + RR_RING + h * RR_BLK + u) * RR_LANES + lane];
-          ring[h * RR_BLK + u].x = (int)(unsigned)q_; ring[h * RR_BLK + u].y = (int)(q_ >> 32);
-        }
-        float va[RR_BLK], vb[RR_BLK], vp[RR_BLK], vo[RR_BLK];
+        for (int j = 0; j < 4; ++j) { vb[j] = lds_ld(b4 + 4 * j); vo[j] = lds_ld(d4[j]); }
+        float t = va;
+        if (DIV) { float r = __builtin_amdgcn_rcpf(vp); r = r * (2.0f - vp * r); t *= r; }
+        const int fl = __builtin_amdgcn_readfirstlane(e.w) >> 8;
+        if (DIV) {       // several contribution ranks per target: accumulate, apply on the flagged row
 #pragma unroll
-        for (int u = 0; u < RR_BLK; ++u) {
-          const int a4 = e[u].x & 0xFFFF;
-          va[u] = lds_ld(a4); vb[u] = lds_ld((int)((unsigned)e[u].x >> 16));
-          vp[u] = DIV ? lds_ld(a4 - ((e[u].y >> 16) & 0xFF) + 4) : 1.0f;
-          vo[u] = lds_ld(e[u].y & 0xFFFF);
-        }
+          for (int j = 0; j < 4; ++j) acc[j] += vb[j] * t;
+          if (fl & 1) {
 #pragma unroll
-        for (int u = 0; u < RR_BLK; ++u) {
-          float t = va[u];
-          if (DIV) { float r = __builtin_amdgcn_rcpf(vp[u]); r = r * (2.0f - vp[u] * r); t *= r; }
-          if (DIV) {       // several contribution ranks per target: accumulate, apply on the flagged row
-            acc += vb[u] * t;
-            if ((__builtin_amdgcn_readfirstlane(e[u].y) >> 24) & 1) { lds_st(e[u].y & 0xFFFF, vo[u] - acc); acc = 0.0f; }
-          } else {         // inversion: one contribution per target and level, every row applies
-            lds_st(e[u].y & 0xFFFF, vo[u] - vb[u] * t);
+            for (int j = 0; j < 4; ++j) { lds_st(d4[j], vo[j] - acc[j]); acc[j] = 0.0f; }
           }
+        } else {         // inversion: one contribution per target and level, every row applies
+#pragma unroll
+          for (int j = 0; j < 4; ++j) lds_st(d4[j], vo[j] - vb[j] * t);
         }
-        if ((__builtin_amdgcn_readfirstlane(e[RR_BLK - 1].y) >> 24) & 2) sync();
+        if (fl & 2) sync();
       }
     }
   }
@@ -786,7 +784,7 @@ struct Wave {
   // rank.  Rows are scaled by 1/D afterwards.
   __device__ __forceinline__ void factor(float damp) {
     for (int e = lane; e < D.nM; e += RR_LANES) s_qLD[e] = s_qM[e];
-    if (lane < 3) s_qLD[D.nM + lane] = lane == 1 ? 1.0f : 0.0f;     // cells ZERO, ONE, TRASH of the level schedules
+    if (lane < 4) s_qLD[D.nM + lane] = lane == 1 ? 1.0f : 0.0f;     // cells ZERO, ONE, TRASH (+ pad) of the level schedules
     sync();
     if (damp != 0.0f) {
 #pragma unroll

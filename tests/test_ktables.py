@@ -53,48 +53,57 @@ def test_mulm_by_solve_jobs(model_and_state):
     np.testing.assert_allclose(y, Md @ x, rtol=1e-12, atol=1e-14)
 
 
-PF = 2          # rows per block of the level schedules (RR_BLK)
-RING = 8        # rows in flight (RR_RING)
+BLK = 1         # rows per block of the level schedules (RR_BLK)
+RING = 4        # rows in flight (RR_RING)
 
 
 def run_levels(L, tab, nrows, div):
-    """numpy restatement of Wave::run_levels: blocks of PF rows; all reads of a block (sources and the old target values)
-    are taken before its writes; a level's sources are never written inside the level.  L carries the three extra cells
-    ZERO, ONE, TRASH behind its nM entries."""
-    nM = len(L) - 3
+    """numpy restatement of Wave::run_levels: blocks of BLK rows of quad operations; all reads of a block (sources and the
+    old target values) are taken before its writes; a level's sources are never written inside the level.  L carries the
+    extra cells ZERO, ONE, TRASH (+ pad) behind its nM entries."""
+    nM = len(L) - 4
     assert L[nM] == 0.0 and L[nM + 1] == 1.0
-    acc = np.zeros(LANES)
+    acc = np.zeros((LANES, 4))
     written, read = set(), set()
     assert nrows % RING == 0 and tab.shape[0] == nrows + RING
-    assert np.all(tab[nrows:, :, 0] == (nM | nM << 16)) and np.all(tab[nrows:, :, 1] == nM + 2)
-    for b0 in range(0, nrows, PF):
+    u32 = tab.view(np.uint32).astype(np.int64)
+    for b0 in range(0, nrows, BLK):
         snap = L.copy()                                   # what the block's batched reads see
-        for u in range(PF):
-            e = tab[b0 + u]
-            fl = e[0, 1] >> 24
-            assert np.all((e[:, 1] >> 24) == fl) and 0 <= fl < 4
-            a, bq, dst, q = e[:, 0] & 0xFFFF, (e[:, 0] >> 16) & 0xFFFF, e[:, 1] & 0xFFFF, (e[:, 1] >> 16) & 0xFF
+        for u in range(BLK):
+            e = u32[b0 + u]
+            fl = int(e[0, 3] >> 8)
+            assert np.all((e[:, 3] >> 8) == fl) and 0 <= fl < 4
+            a, b_ = e[:, 0] & 0xFFFF, e[:, 0] >> 16
+            d = np.stack([e[:, 1] & 0xFFFF, e[:, 1] >> 16, e[:, 2] & 0xFFFF, e[:, 2] >> 16], axis=1)
+            q = e[:, 3] & 0xFF
             real = a != nM
-            assert np.all(bq[~real] == nM) and np.all(q[~real] == 0) and np.all(dst[real] < nM)
-            read.update(a[real].tolist()); read.update(bq[real].tolist())
+            assert np.all(b_[~real] == nM) and np.all(q[~real] == 0)
+            valid = d < nM                                # targets of short runs and of empty operations go to TRASH
+            assert np.all(d[~valid] == nM + 2) and np.all(valid[real, 0])
+            assert np.all(valid[:, :-1] >= valid[:, 1:])  # the valid targets of a quad come first
+            read.update(a[real].tolist())
+            for j in range(4):
+                read.update((b_ + j)[valid[:, j] & real].tolist())
             if div:
                 piv = a + 1 - q
                 assert np.all(piv[~real] == nM + 1) and np.all(piv[real] < nM)
                 read.update(piv[real].tolist())
-                acc += snap[bq] * (snap[a] / snap[piv])
+                t = snap[a] / snap[piv]
             else:
                 assert np.all(q == 0)
-                acc += snap[bq] * snap[a]
-            if fl & 1:
-                has = dst < nM
-                t = dst[has]
-                assert np.all(dst[~has] == nM + 2) and np.all(acc[~has] == 0.0)
-                assert len(set(t.tolist())) == len(t)     # plain RMW: no two lanes share a target
-                assert not (set(t.tolist()) & written)    # one write per target and level
-                written.update(t.tolist())
-                L[dst] = snap[dst] - acc                  # lanes without a target rewrite TRASH with itself
+                t = snap[a]
+            assert np.all(b_[real] + 3 < len(L))
+            for j in range(4):
+                acc[:, j] += snap[np.minimum(b_ + j, len(L) - 1)] * t
+            if fl & 1 or not div:
+                tg = d[valid]
+                assert len(set(tg.tolist())) == len(tg)   # plain RMW: no two lanes / slots share a target
+                assert not (set(tg.tolist()) & written)   # one write per target and level
+                written.update(tg.tolist())
+                L[tg] = snap[tg] - acc[valid]
                 acc[:] = 0.0
-            assert not (fl & 2) or u == PF - 1            # levels end at block ends
+                L[nM:] = [0.0, 1.0, 0.0, 0.0]             # whatever landed in TRASH is never used
+            assert not (fl & 2) or u == BLK - 1           # levels end at block ends
             if fl & 2:
                 assert not (written & read)               # reads of a level never see its writes
                 assert np.all(acc == 0.0)
@@ -104,7 +113,7 @@ def run_levels(L, tab, nrows, div):
 
 def kernel_factor(m, qM):
     """numpy restatement of Wave::factor: gather rows by target entry (k_factor3), then the row scaling by 1/D."""
-    L = run_levels(np.concatenate([qM, [0.0, 1.0, 0.0]]), m["k_factor3"], int(m["k_factor3_rows"]), True)[:len(qM)]
+    L = run_levels(np.concatenate([qM, [0.0, 1.0, 0.0, 0.0]]), m["k_factor3"], int(m["k_factor3_rows"]), True)[:len(qM)]
     Madr = m["k_dof_i"][:, 4]
     dinv = 1.0 / L[Madr]
     ij = m["k_M_ij"]
@@ -116,7 +125,7 @@ def kernel_factor(m, qM):
 
 def kernel_invert(m, L):
     """numpy restatement of Wave::invert: W = I - L^-1 in place (k_linv)."""
-    return run_levels(np.concatenate([L, [0.0, 1.0, 0.0]]), m["k_linv"], int(m["k_linv_rows"]), False)[:len(L)]
+    return run_levels(np.concatenate([L, [0.0, 1.0, 0.0, 0.0]]), m["k_linv"], int(m["k_linv_rows"]), False)[:len(L)]
 
 
 def kernel_solve(m, W, dinv, b):
