@@ -19,7 +19,7 @@
 #define RR_LANES 64
 #define RR_DOFI 12   // ints per dof in k_dof_i
 #define RR_BODYI 12  // ints per body in k_body_i
-#define RR_RING 4    // rows of a level schedule in flight (ktables RING)
+#define RR_RING 8    // rows of a level schedule in flight (ktables RING)
 #define RR_NPH 16    // phases of the diagnostic (s_memtime) build
 #define RR_MINVAL 1e-15f
 #define RR_MINIMP 0.0001f

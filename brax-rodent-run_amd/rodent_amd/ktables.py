@@ -152,7 +152,7 @@ def build_kernel_tables(m):
     # kernel needs no predicates.  flags: 1 = apply the lane's accumulated sums to d*, 2 = level ends (LDS hand-off); they
     # are the same in all 64 lanes of a row.
     ZERO, TRASH = nM, nM + 2
-    BLK, RING = 1, 4          # rows per block (RR_BLK), rows in flight (RR_RING)
+    BLK, RING = 1, 8          # rows per block (RR_BLK), rows in flight (RR_RING)
 
     def quads(a_, b_start, d_start, n, q_):
         """cut a run of n consecutive (source b, target d) pairs sharing the operand a_ into quad operations"""

@@ -54,7 +54,7 @@ def test_mulm_by_solve_jobs(model_and_state):
 
 
 BLK = 1         # rows per block of the level schedules (RR_BLK)
-RING = 4        # rows in flight (RR_RING)
+RING = 8        # rows in flight (RR_RING)
 
 
 def run_levels(L, tab, nrows, div):
