@@ -8,10 +8,11 @@
 //
 // Mapping: lanes run over bodies / dofs / contacts (element e -> lane e%64, slot e/64,
 // slot counts are template parameters so per-lane arrays stay in registers).  Kinematic-tree
-// recursions are level-synchronous sweeps; the sparse L'DL factor/solve, M*x and J'f products are
-// driven by the lane-major index tables built in rodent_amd/ktables.py.  Reductions over dofs / rows
-// are wavefront butterflies.  Inactive constraint rows contribute exactly zero in the reference
-// formulation, so they are skipped.
+// recursions are pointer-doubling / DFS-range sweeps; the sparse L'DL factorisation and its explicit
+// inverse run as level schedules, the solves and M*x as balanced per-lane jobs (tables built in
+// rodent_amd/ktables.py); J*x and J'f are Jacobian-free.  No LDS atomics: every update has one owner
+// lane.  Reductions over dofs / rows are DPP wave sums in a fixed order.  Inactive constraint rows
+// contribute exactly zero in the reference formulation, so they are skipped.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
