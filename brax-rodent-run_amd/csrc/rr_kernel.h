@@ -319,8 +319,6 @@ struct Wave {
   BodyC bc0;              // constants of body `lane` (slot 0)
   int banc[NBS][2];       // 2^k-th ancestors of the slot's body, k = 0..7, one byte each (0 = none)
   int blast[NBS];         // last body of the subtree (bodies are in DFS order)
-  static constexpr int NME = NVS == 1 ? 10 : (NVS == 2 ? 18 : 35);   // sparse-M entries per lane (nM <= 64*NME)
-  int ment[NME];          // entry e = lane + 64*it of qM: row i | col j << 8, -1 beyond nM
   int dofc0[NVS], dofc1[NVS];   // packed per-dof constants: depth | kind<<8 | root<<12 | body<<16 | parent-of-body<<24 ; Madr | last_desc<<16
   int con_chain[NCS][9];  // ancestor dof chain of the contact's body, leaf first, 4 dof ids per register
   // per-dof registers (slot s -> dof lane + 64 s)
@@ -701,6 +699,12 @@ struct Wave {
     sync();
   }
 
+  static constexpr int NME = NVS == 1 ? 10 : (NVS == 2 ? 18 : 35);   // sparse-M entries per lane (nM <= 64*NME)
+  __device__ __forceinline__ void load_ment(int* ment) {
+    const int ol = opaque(lane);
+#pragma unroll
+    for (int it = 0; it < NME; ++it) ment[it] = g_int(T.M_ij_k, ol + RR_LANES * it);
+  }
   // ---------------------------------------------------------------- A-3 qM (sparse) from crb and cdof
   __device__ __forceinline__ void mass_matrix() {
 #pragma unroll
@@ -708,10 +712,12 @@ struct Wave {
       const int d = lane + RR_LANES * s;
       if (d < D.nv) mul_inert_vec(s_buf + 6 * d, s_crb + 10 * ((opaque(dofc0[s]) >> 16) & 255), s_cdof + 6 * d);
     }
+    int ment[NME];          // entry e = lane + 64*it of qM: row i | col j << 8, -1 beyond nM (table padded to whole rows)
+    load_ment(ment);
     sync();
 #pragma unroll
     for (int it = 0; it < NME; ++it) {
-      const int ij = opaque(ment[it]);
+      const int ij = ment[it];
       if (ij >= 0) {
         const int i = ij & 255, j = ij >> 8;
         float v = dot6(s_cdof + 6 * j, s_buf + 6 * i);
@@ -784,6 +790,8 @@ struct Wave {
   // targets and sums its contributions L_kp L_kq / D_k over the level's dofs k below it, one table row per contribution
   // rank.  Rows are scaled by 1/D afterwards.
   __device__ __forceinline__ void factor(float damp) {
+    int ment[NME];          // for the row scaling at the end; requested now, local to this call (not held across the solver)
+    load_ment(ment);
     for (int e = lane; e < D.nM; e += RR_LANES) s_qLD[e] = s_qM[e];
     if (lane < 4) s_qLD[D.nM + lane] = lane == 1 ? 1.0f : 0.0f;     // cells ZERO, ONE, TRASH (+ pad) of the level schedules
     sync();
@@ -806,7 +814,7 @@ struct Wave {
     sync();
 #pragma unroll
     for (int it = 0; it < NME; ++it) {
-      const int ij = opaque(ment[it]);
+      const int ij = ment[it];
       if (ij >= 0) {
         const int i = ij & 255, j = ij >> 8;
         if (i != j) s_qLD[lane + RR_LANES * it] *= s_arm[D.nv + i];
@@ -1594,13 +1602,8 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
       for (int e = lane; e < 10 * D.nbody; e += RR_LANES) dg[D.g_crb + e] = w.s_crb[e];
       for (int e = lane; e < 6 * D.nbody; e += RR_LANES) dg[D.g_cfrc + e] = w.s_cfrc[e];
     }
-    {   // sparse-matrix entry ids and contact chains: needed from here to the end of the substep
+    {   // contact chains: needed from here to the end of the substep
       const int ol = opaque(lane);
-#pragma unroll
-      for (int it = 0; it < Wave<NBS, NVS, NCS, DT>::NME; ++it) {
-        const int e = ol + RR_LANES * it;
-        w.ment[it] = e < D.nM ? T.M_ij_k[e] : -1;
-      }
 #pragma unroll
       for (int cs = 0; cs < NCS; ++cs)
 #pragma unroll

@@ -130,7 +130,7 @@ def build_kernel_tables(m):
         for p, j in enumerate(chain):
             M_ij[Madr[i] + p] = i | (int(j) << 16)
     # kernel layout: row | col << 8 per entry, padded with -1 to whole 64-lane rows plus one row of slack (prefetch)
-    nrow = (nM + LANES - 1) // LANES + 1
+    nrow = max((nM + LANES - 1) // LANES + 1, {1: 10, 2: 18, 3: 35}.get(NVS, 35))   # the kernel reads Wave::NME whole rows
     mk = np.full(nrow * LANES, -1, np.int32)
     mk[:nM] = (M_ij & 0xFFFF) | ((M_ij >> 16) << 8)
     k["k_M_ij"] = M_ij
