@@ -203,13 +203,21 @@ static int upload_levels(rr_batch* b, const char* name, rr_gi* dst) {
 }
 
 typedef void (*kern_t)(const RRDims, const RRTables, const RRIO, const int, const int);
-static kern_t pick_kernel(const rr_model* m, bool prof = false) {
+// Instances: production (no debug dump; fixed-dimension variant for the rodent dims), debug dump (generic dims; selected per
+// launch when rr_outputs.debug is given), cycle-stamp profile (diagnostic, rodent dims or generic 2,2,1).
+static kern_t pick_kernel(const rr_model* m, bool prof = false, bool dbg = false) {
   const int nbs = m->NBS, nvs = m->NVS, ncs = m->NCS;
-  if (prof) return (nbs == 2 && nvs == 2 && ncs == 1) ? (RRDimsRodent::matches(m->kd) ? rr_step_kernel<2, 2, 1, true, RRDimsRodent> : rr_step_kernel<2, 2, 1, true, RRDims>) : nullptr;
-  if (nbs == 2 && nvs == 2 && ncs == 1 && RRDimsRodent::matches(m->kd)) return rr_step_kernel<2, 2, 1, false, RRDimsRodent>;   // fixed-dimension instance
-  if (nbs == 1 && nvs == 1 && ncs == 1) return rr_step_kernel<1, 1, 1, false, RRDims>;
-  if (nbs == 2 && nvs == 2 && ncs == 1) return rr_step_kernel<2, 2, 1, false, RRDims>;
-  if (nbs == 3 && nvs == 3 && ncs == 2) return rr_step_kernel<3, 3, 2, false, RRDims>;
+  if (prof) return (nbs == 2 && nvs == 2 && ncs == 1) ? (RRDimsRodent::matches(m->kd) ? rr_step_kernel<2, 2, 1, true, false, RRDimsRodent> : rr_step_kernel<2, 2, 1, true, false, RRDims>) : nullptr;
+  if (dbg) {
+    if (nbs == 1 && nvs == 1 && ncs == 1) return rr_step_kernel<1, 1, 1, false, true, RRDims>;
+    if (nbs == 2 && nvs == 2 && ncs == 1) return rr_step_kernel<2, 2, 1, false, true, RRDims>;
+    if (nbs == 3 && nvs == 3 && ncs == 2) return rr_step_kernel<3, 3, 2, false, true, RRDims>;
+    return nullptr;
+  }
+  if (nbs == 2 && nvs == 2 && ncs == 1 && RRDimsRodent::matches(m->kd)) return rr_step_kernel<2, 2, 1, false, false, RRDimsRodent>;   // fixed-dimension instance
+  if (nbs == 1 && nvs == 1 && ncs == 1) return rr_step_kernel<1, 1, 1, false, false, RRDims>;
+  if (nbs == 2 && nvs == 2 && ncs == 1) return rr_step_kernel<2, 2, 1, false, false, RRDims>;
+  if (nbs == 3 && nvs == 3 && ncs == 2) return rr_step_kernel<3, 3, 2, false, false, RRDims>;
   return nullptr;
 }
 
@@ -230,8 +238,10 @@ extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t devi
   kern_t kern = pick_kernel(m);
   if (!m->stage_ok) { rr_batch_destroy(b); return fail(RR_EUNSUPPORTED, "rr_batch_create: 4*ncon + nv exceeds the line-search staging cells (6*nbody)"); }
   if (m->dims.lds_bytes > 64 * 1024) { rr_batch_destroy(b); return fail(RR_EUNSUPPORTED, "rr_batch_create: per-env working set exceeds 160 KiB LDS"); }
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, m->dims.lds_bytes);
-  if (e != hipSuccess) { rr_batch_destroy(b); return fail(RR_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
+  for (kern_t kk : {kern, pick_kernel(m, false, true)}) {   // production and debug-dump instances
+    hipError_t e = hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, m->dims.lds_bytes);
+    if (e != hipSuccess) { rr_batch_destroy(b); return fail(RR_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
+  }
   *out = b;
   return RR_OK;
 }
@@ -276,7 +286,7 @@ static int launch(rr_batch* b, const rr_state* st, const float* ctrl, int n_fram
   }
   io.mode = mode;
   HIPCHK(hipSetDevice(b->device));
-  kern_t kern = pick_kernel(b->m, b->prof != nullptr);
+  kern_t kern = pick_kernel(b->m, b->prof != nullptr, io.dbg != nullptr);
   if (!kern) return fail(RR_EUNSUPPORTED, "launch: no diagnostic kernel instance for this model");
   io.prof = b->prof;
   RRDims kd = b->kd;

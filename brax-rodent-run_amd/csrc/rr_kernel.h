@@ -1482,7 +1482,7 @@ static __device__ __forceinline__ RRIO load_io() {
 #endif
 }
 
-template <int NBS, int NVS, int NCS, bool PROF, class DT>
+template <int NBS, int NVS, int NCS, bool PROF, bool DBG, class DT>
 __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(const RRDims Dk, const RRTables T, const RRIO io_kernarg, const int num_envs,
                                                            const int n_frames) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1495,7 +1495,8 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
   const int lane = threadIdx.x;
   RRIO io = load_io();
   const int mode = io.mode;
-  float* dbg = io.dbg ? io.dbg + (size_t)env * D.dbg_floats : nullptr;
+  // the debug dump (parity tests) is a separate instance: its paths keep dozens of values alive across the solver
+  float* dbg = (DBG && io.dbg) ? io.dbg + (size_t)env * D.dbg_floats : nullptr;
 
   // ---- load state
   for (int i = lane; i < D.nq; i += RR_LANES) w.s_qpos[i] = io.qpos[(size_t)env * D.nq + i];

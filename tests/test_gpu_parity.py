@@ -73,8 +73,12 @@ def test_forward_stages_match_oracle(model_name, oracle_built):
     assert not bad, bad
 
 
-def test_solver_and_substep_match_oracle(oracle_built):
-    """qacc after the CG solve and qpos/qvel after one substep, same inputs (float32 vs float64 oracle)."""
+@pytest.mark.parametrize("instance", ["debug_dump", "production"])
+def test_solver_and_substep_match_oracle(oracle_built, instance):
+    """qacc after the CG solve and qpos/qvel after one substep, same inputs (float32 vs float64 oracle), for both kernel
+    instances: the debug-dump instance (generic dimensions) that the stage tests read, and the production instance (no
+    dump, fixed rodent dimensions) that is timed.  The two differ in instruction selection (constant folding / FMA
+    contraction), so their outputs differ at rounding level; each must meet the same bounds against the oracle."""
     from rodent_amd import assets, hip
     ref = oracle_built
     N = 48
@@ -84,19 +88,23 @@ def test_solver_and_substep_match_oracle(oracle_built):
     ctrl = np.random.default_rng(6).uniform(-1, 1, (N, M.nu))
     ds = _to_dev(st, dev)
     dbg = torch.zeros(N, batch.dims.dbg_floats, device=dev)
-    batch.pipeline_step(ds, torch.tensor(ctrl, dtype=torch.float32, device=dev), 1, out=dict(debug=dbg))
+    batch.pipeline_step(ds, torch.tensor(ctrl, dtype=torch.float32, device=dev), 1,
+                        out=dict(debug=dbg) if instance == "debug_dump" else None)
     torch.cuda.synchronize()
     lay = batch.debug_layout()
     dbg = dbg.cpu().numpy().astype(np.float64)
+    got_qacc = ds["qacc_warmstart"].cpu().numpy().astype(np.float64)      # the warm start handed on IS the solver's qacc
     err_qacc, err_qvel, err_qpos, err_f = [], [], [], []
     for e in range(N):
         d = util.oracle_forward(ref, M, st, e, ctrl[e])
-        o, n = lay["qacc"]
         qacc = d.get("qacc")
-        err_qacc.append(np.abs(dbg[e, o:o + n] - qacc).max() / max(np.abs(qacc).max(), 1.0))
-        o, n = lay["qfrc_constraint"]
-        fc = d.get("qfrc_constraint")
-        err_f.append(np.abs(dbg[e, o:o + n] - fc).max() / max(np.abs(fc).max(), 1e-3))
+        err_qacc.append(np.abs(got_qacc[e] - qacc).max() / max(np.abs(qacc).max(), 1.0))
+        if instance == "debug_dump":
+            o, n = lay["qacc"]
+            np.testing.assert_array_equal(dbg[e, o:o + n].astype(np.float32), got_qacc[e].astype(np.float32))
+            o, n = lay["qfrc_constraint"]
+            fc = d.get("qfrc_constraint")
+            err_f.append(np.abs(dbg[e, o:o + n] - fc).max() / max(np.abs(fc).max(), 1e-3))
         d2 = ref.RefData(M)
         for k in ("qpos", "qvel", "act", "qacc_warmstart"):
             d2.set(k, st[k][e])
@@ -104,10 +112,12 @@ def test_solver_and_substep_match_oracle(oracle_built):
         dv = np.abs(d2.get("qvel") - st["qvel"][e]).max()           # scale: the substep's velocity change
         err_qvel.append(np.abs(ds["qvel"][e].cpu().numpy() - d2.get("qvel")).max() / max(dv, 1e-3))
         err_qpos.append(np.abs(ds["qpos"][e].cpu().numpy() - d2.get("qpos")).max())
-    print("qacc rel err: median %.2e max %.2e | qfrc_constraint rel: median %.2e max %.2e | qvel err / max|dqvel| max %.2e | qpos abs max %.2e"
-          % (np.median(err_qacc), np.max(err_qacc), np.median(err_f), np.max(err_f), np.max(err_qvel), np.max(err_qpos)))
+    print("%s: qacc rel err: median %.2e max %.2e | qvel err / max|dqvel| max %.2e | qpos abs max %.2e"
+          % (instance, np.median(err_qacc), np.max(err_qacc), np.max(err_qvel), np.max(err_qpos)))
     # a truncated (8-iteration) CG run in float32 vs float64: branchy line search -> allow a few outliers
     assert np.median(err_qacc) < 2e-3
-    assert np.max(err_qacc) < 1e-3 and np.max(err_f) < 5e-3
+    assert np.max(err_qacc) < 1e-3
+    if err_f:
+        assert np.max(err_f) < 5e-3
     assert np.max(err_qpos) < 5e-5
     assert np.median(err_qvel) < 1e-4 and np.max(err_qvel) < 2e-3
