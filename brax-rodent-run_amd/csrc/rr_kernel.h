@@ -21,7 +21,7 @@
 #define RR_DOFI 12   // ints per dof in k_dof_i
 #define RR_BODYI 12  // ints per body in k_body_i
 #define RR_RING 8    // rows of a level schedule in flight (ktables RING)
-#define RR_NPH 16    // phases of the diagnostic (s_memtime) build
+#define RR_NPH 24    // phases of the diagnostic (s_memtime) build
 #define RR_MINVAL 1e-15f
 #define RR_MINIMP 0.0001f
 #define RR_MAXIMP 0.9999f
@@ -1275,11 +1275,13 @@ struct Wave {
   // (Jaref, Jv, D) triples are compacted once per line search through LDS (positions by ballot / mbcnt; the staging cells
   // are the dead cinert / cvel / pose regions), so that every evaluation of the up to 2 + 3*ls_iterations points costs one
   // row per lane instead of 4*NCS + NVS.
+  template <bool PROF>
   __device__ __forceinline__ void linesearch() {
     float red[4] = {0, 0, 0, 0};
     put_vec(search);   // mv = M search is carried by the caller's recurrence
     for (int rep = 0; rep < RR_REP_JAC; ++rep) jac_mul(con_jv, s_vec);
     jac_mul(con_jv, s_vec);
+    stamp<PROF>(16);
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
       lim_jv[s] = lim_sign[s] * search[s];
@@ -1323,12 +1325,14 @@ struct Wave {
     const float smag = sqrtf(red[0]) * D.meaninertia * (float)(D.nv > 1 ? D.nv : 1);
     const float gtol = D.tolerance * D.ls_tolerance * smag;
     const float qg[3] = {gauss, red[1] - red[2], 0.5f * red[3]};
+    stamp<PROF>(17);
     LSPoint p0, lo, hi, tmp3[3];
     float a1[1] = {0.0f};
     ls_eval<1>(a1, qg, &p0, R, rjr, rjv, rD);
     a1[0] = p0.alpha - p0.d0 / p0.d1;
     ls_eval<1>(a1, qg, &lo, R, rjr, rjv, rD);
     if (lo.d0 < p0.d0) { hi = p0; } else { hi = lo; lo = p0; }
+    stamp<PROF>(18);
     bool swap = true;
     for (int it = 0; it < D.ls_iterations; ++it) {
       bool done = !swap;
@@ -1348,6 +1352,7 @@ struct Wave {
       if (swap_hi_mid) hi = mid;
       swap = swap_lo_next || swap_lo_mid || swap_hi_next || swap_hi_mid;
     }
+    stamp<PROF>(19);
     const bool improved = uni((lo.cost < p0.cost) || (hi.cost < p0.cost));
     const float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
     if (improved) {
@@ -1395,8 +1400,8 @@ struct Wave {
       done |= gradient < D.tolerance;
       if (uni(done)) break;
       stamp<PROF>(12);
-      for (int rep = 0; rep < RR_REP_LS; ++rep) linesearch();
-      linesearch();
+      for (int rep = 0; rep < RR_REP_LS; ++rep) linesearch<false>();
+      linesearch<PROF>();
       stamp<PROF>(9);
       float pm[NVS], gg = 0.0f;
 #pragma unroll

@@ -11,12 +11,12 @@ state=env.reset(0)
 for _ in range(30): state=env.step(state, torch.rand(N,30,device=dev)*2-1)
 ps=state.pipeline_state
 st=dict(qpos=ps.qpos.clone(), qvel=ps.qvel.clone(), act=ps.act.clone(), qacc_warmstart=ps.qacc_warmstart.clone())
-buf=torch.zeros(N,16,dtype=torch.int64,device=dev)
+buf=torch.zeros(N,24,dtype=torch.int64,device=dev)
 b=env._batch; b.set_profile(buf)
 b.pipeline_step(st, torch.rand(N,30,device=dev)*2-1, 10)
 torch.cuda.synchronize()
 c=buf.cpu().numpy().astype(np.float64)
-names=['kinematics','com_pos','velocity_sweep','backward_sweep','mass_matrix','factor','smooth+solve','constraints','solver_init(3 ctx)','linesearch','update_constraint','update_gradient','cg_misc','euler(factor+solve)','epilogue','frame_head']
+names=['kinematics','com_pos','velocity_sweep','backward_sweep','mass_matrix','factor','smooth+solve','constraints','solver_init(3 ctx)','linesearch','update_constraint','update_gradient','cg_misc','euler(factor+solve)','epilogue','frame_head','ls: put_vec+jac_mul','ls: staging+sums','ls: 2 first points','ls: iterations','-','-','-','-']
 tot=c.sum(1)
 print(f'N={N} envs, 10 substeps; cycles per env (median over envs): total {np.median(tot):.0f}')
 for i,n in enumerate(names):
