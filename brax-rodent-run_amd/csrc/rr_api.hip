@@ -42,13 +42,13 @@ struct rr_model {
 static void layout(rr_model* m) {
   RRDims& k = m->kd;
   const rr_dims& d = m->dims;
-  const RRLayout L = rr_layout(d.nq, d.nv, d.nu, d.nbody, d.nM);
+  const RRLayout L = rr_layout(d.nq, d.nv, d.nu, d.nbody, d.nM, d.ncon);
   k.o_qpos = L.o_qpos; k.o_qvel = L.o_qvel; k.o_act = L.o_act; k.o_ctrl = L.o_ctrl; k.o_xpos = L.o_xpos; k.o_xquat = L.o_xquat;
   k.o_cinert = L.o_cinert; k.o_cdof = L.o_cdof; k.o_cvel = L.o_cvel; k.o_qM = L.o_qM; k.o_qLD = L.o_qLD; k.o_vec = L.o_vec; k.o_x = L.o_x;
-  k.o_arm = L.o_arm; k.o_warm = L.o_warm; k.o_qact = L.o_qact; k.o_base = L.o_base; k.lds_floats = L.lds_floats;
+  k.o_arm = L.o_arm; k.o_warm = L.o_warm; k.o_qact = L.o_qact; k.o_base = L.o_base; k.o_jlist = L.o_jlist; k.lds_floats = L.lds_floats;
   const int o = L.lds_floats;
   // staging of the line search's compacted rows: cinert | cvel | pose regions each hold 4*ncon + nv floats
-  m->stage_ok = 4 * d.ncon + d.nv <= std::min(std::min(10 * d.nbody, 6 * d.nbody), std::max(7 * d.nbody + 4, 6 * d.nv));
+  m->stage_ok = 6 * d.ncon <= std::max(7 * d.nbody + 4, 6 * d.nv) && 4 * d.ncon + d.nv <= std::min(std::min(10 * d.nbody, 6 * d.nbody), std::max(7 * d.nbody + 4, 6 * d.nv));
   // debug dump
   int g = 0;
   auto dbg = [&](const char* name, int n) { int r = g; m->dbg_names.push_back(name); m->dbg_off.push_back(g); m->dbg_size.push_back(n); g += n; return r; };
@@ -99,7 +99,7 @@ extern "C" int rr_model_load(const char* path, rr_model** out) {
   static const char* need[] = {"nq", "nv", "nu", "nbody", "njnt", "ngeom", "nM", "ncon", "nlimit", "nefc", "obs_dim", "k_slots",
                                "k_body_i", "k_body_f", "k_jnt_i", "k_jnt_f", "k_dof_i", "k_dof_f", "k_act_f", "k_M_ij_k", "k_body_anc",
                                "k_nround", "k_factor3", "k_factor3_rows", "k_linv", "k_linv_rows", "k_coljob", "k_rowjob", "k_rowjob_chain",
-                               "k_jobown", "k_solve_lmax", "k_dof_base", "k_con_i", "k_con_f", "k_con_chain_packed", "k_root_mass",
+                               "k_jobown", "k_solve_lmax", "k_dof_base", "k_con_i", "k_con_f", "k_con_chain_packed", "k_con_chain_rows", "k_root_mass",
                                "dof_depth", "body_depth", "opt_timestep", "opt_gravity", "stat_meaninertia"};
   for (const char* nme : need)
     if (!m->find(nme)) { std::string s = std::string("rr_model_load: blob lacks '") + nme + "'"; delete m; return fail(RR_EIO, s); }
@@ -230,7 +230,7 @@ extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t devi
   int rc = 0;
 #define UP(field, name) if ((rc = upload(b, name, &b->T.field))) { rr_batch_destroy(b); return rc; }
   UP(body_i, "k_body_i") UP(jnt_i, "k_jnt_i") UP(dof_i, "k_dof_i") UP(M_ij_k, "k_M_ij_k")
-  UP(body_anc, "k_body_anc") UP(con_chain_packed, "k_con_chain_packed") UP(coljob, "k_coljob") UP(rowjob, "k_rowjob") UP(rowjob_chain, "k_rowjob_chain") UP(jobown, "k_jobown") UP(dof_base, "k_dof_base") UP(con_i, "k_con_i")
+  UP(body_anc, "k_body_anc") UP(con_chain_rows, "k_con_chain_rows") UP(coljob, "k_coljob") UP(rowjob, "k_rowjob") UP(rowjob_chain, "k_rowjob_chain") UP(jobown, "k_jobown") UP(dof_base, "k_dof_base") UP(con_i, "k_con_i")
   UP(body_f, "k_body_f") UP(jnt_f, "k_jnt_f") UP(dof_f, "k_dof_f")
   UP(act_f, "k_act_f") UP(con_f, "k_con_f") UP(root_mass, "k_root_mass")
 #undef UP

@@ -32,7 +32,7 @@ struct RRDims {
   float dt, gx, gy, gz, tolerance, ls_tolerance, meaninertia;
   // LDS offsets (floats)
   int o_qpos, o_qvel, o_act, o_ctrl, o_xpos, o_xquat, o_cinert, o_cdof, o_cvel,
-      o_qM, o_qLD, o_vec, o_x, o_arm, o_warm, o_qact, o_base, lds_floats;
+      o_qM, o_qLD, o_vec, o_x, o_arm, o_warm, o_qact, o_base, o_jlist, lds_floats;
   // debug dump offsets (floats)
   int g_xpos, g_xquat, g_xmat, g_com, g_cinert, g_crb, g_cdof, g_cvel, g_cfrc, g_qM, g_qLD, g_dinv, g_bias, g_passive,
       g_actuator, g_smooth, g_qacc_smooth, g_con_dist, g_con_pos, g_con_frame, g_con_D, g_con_aref, g_lim, g_qacc,
@@ -42,11 +42,11 @@ struct RRDims {
 // LDS layout of one environment (float offsets).  One constexpr function serves the host (rr_api.hip layout) and the
 // kernel instance compiled for fixed model dimensions.
 struct RRLayout {
-  int o_qpos, o_qvel, o_act, o_ctrl, o_xpos, o_xquat, o_cinert, o_cdof, o_cvel, o_qM, o_qLD, o_vec, o_x, o_arm, o_warm, o_qact, o_base, lds_floats;
+  int o_qpos, o_qvel, o_act, o_ctrl, o_xpos, o_xquat, o_cinert, o_cdof, o_cvel, o_qM, o_qLD, o_vec, o_x, o_arm, o_warm, o_qact, o_base, o_jlist, lds_floats;
 };
 constexpr int rr_imax(int a, int b) { return a > b ? a : b; }
 constexpr int rr_up4(int n) { return (n + 3) & ~3; }
-constexpr RRLayout rr_layout(int nq, int nv, int nu, int nbody, int nM) {
+constexpr RRLayout rr_layout(int nq, int nv, int nu, int nbody, int nM, int ncon) {
   RRLayout k{};
   int o = 0;
   k.o_qpos = o; o += rr_up4(nq);
@@ -67,6 +67,7 @@ constexpr RRLayout rr_layout(int nq, int nv, int nu, int nbody, int nM) {
   k.o_warm = o; o += rr_up4(nv);
   k.o_qact = o; o += rr_up4(nv);
   k.o_base = o; o += rr_up4(nv);
+  k.o_jlist = o; o += rr_up4(ncon);      // ids of the contacts in penetration, by rank (J*x jobs)
   k.lds_floats = o;
   return k;
 }
@@ -77,10 +78,11 @@ constexpr RRLayout rr_layout(int nq, int nv, int nu, int nbody, int nM) {
 // (solver options, table row counts, debug offsets) stays run-time.  The host selects it only when every constant matches.
 struct RRDimsRodent : RRDims {
   static constexpr int nq = 74, nv = 73, nu = 30, nbody = 66, njnt = 68, nM = 1119, ncon = 59, dmax = 35, nroot = 1, obs_dim = 1263, nround = 6;
-  static constexpr RRLayout LY = rr_layout(nq, nv, nu, nbody, nM);
+  static constexpr RRLayout LY = rr_layout(nq, nv, nu, nbody, nM, ncon);
   static constexpr int o_qpos = LY.o_qpos, o_qvel = LY.o_qvel, o_act = LY.o_act, o_ctrl = LY.o_ctrl, o_xpos = LY.o_xpos, o_xquat = LY.o_xquat,
                        o_cinert = LY.o_cinert, o_cdof = LY.o_cdof, o_cvel = LY.o_cvel, o_qM = LY.o_qM, o_qLD = LY.o_qLD, o_vec = LY.o_vec,
-                       o_x = LY.o_x, o_arm = LY.o_arm, o_warm = LY.o_warm, o_qact = LY.o_qact, o_base = LY.o_base, lds_floats = LY.lds_floats;
+                       o_x = LY.o_x, o_arm = LY.o_arm, o_warm = LY.o_warm, o_qact = LY.o_qact, o_base = LY.o_base, o_jlist = LY.o_jlist,
+                       lds_floats = LY.lds_floats;
   __host__ __device__ RRDimsRodent(const RRDims& d) : RRDims(d) {}
   static bool matches(const RRDims& d) {
     const RRDims& r = d;
@@ -88,7 +90,7 @@ struct RRDimsRodent : RRDims {
            r.nroot == nroot && r.obs_dim == obs_dim && r.nround == nround && r.o_qpos == o_qpos && r.o_qvel == o_qvel && r.o_act == o_act &&
            r.o_ctrl == o_ctrl && r.o_xpos == o_xpos && r.o_xquat == o_xquat && r.o_cinert == o_cinert && r.o_cdof == o_cdof &&
            r.o_cvel == o_cvel && r.o_qM == o_qM && r.o_qLD == o_qLD && r.o_vec == o_vec && r.o_x == o_x && r.o_arm == o_arm &&
-           r.o_warm == o_warm && r.o_qact == o_qact && r.o_base == o_base && r.lds_floats == lds_floats;
+           r.o_warm == o_warm && r.o_qact == o_qact && r.o_base == o_base && r.o_jlist == o_jlist && r.lds_floats == lds_floats;
   }
 };
 
@@ -96,7 +98,7 @@ struct RRDimsRodent : RRDims {
 typedef const int __attribute__((address_space(1)))* rr_gi;
 typedef const float __attribute__((address_space(1)))* rr_gf;
 struct RRTables {
-  rr_gi factor3, linv, coljob, rowjob, rowjob_chain, jobown, dof_base, body_i, jnt_i, dof_i, M_ij_k, body_anc, con_chain_packed, con_i;
+  rr_gi factor3, linv, coljob, rowjob, rowjob_chain, jobown, dof_base, body_i, jnt_i, dof_i, M_ij_k, body_anc, con_chain_rows, con_i;
   rr_gf body_f, jnt_f, dof_f, act_f, con_f, root_mass;
 };
 
@@ -310,6 +312,7 @@ struct Wave {
   // s_buf reuses xpos|xquat after the contact geometry has been taken.
   float *s_qpos, *s_qvel, *s_act, *s_ctrl, *s_xpos, *s_xquat, *s_cinert, *s_crb, *s_cdof, *s_cvel, *s_cacc,
       *s_cfrc, *s_buf, *s_sc, *s_qM, *s_qLD, *s_vec, *s_x, *s_arm, *s_warm, *s_qact;
+  int* s_jlist;           // contact ids by rank (J*x jobs)
   int* s_base;            // Madr + depth per dof (entry (i, j) of a descendant i of j sits at s_base[i] - depth[j])
 
   static constexpr int W = NVS * RR_LANES;
@@ -320,7 +323,12 @@ struct Wave {
   int banc[NBS][2];       // 2^k-th ancestors of the slot's body, k = 0..7, one byte each (0 = none)
   int blast[NBS];         // last body of the subtree (bodies are in DFS order)
   int dofc0[NVS], dofc1[NVS];   // packed per-dof constants: depth | kind<<8 | root<<12 | body<<16 | parent-of-body<<24 ; Madr | last_desc<<16
-  int con_chain[NCS][9];  // ancestor dof chain of the contact's body, leaf first, 4 dof ids per register
+  // J*x jobs (contact_jobs): the ancestor chains of the contacts in penetration are cut into pieces, one per lane
+  int jch[NCS][9];        // dof ids of this lane's piece, 4 per register
+  int jn[NCS];            // entries of the piece (0 = no job)
+  int con_rank[NCS];      // rank of this lane's contact among the contacts in penetration
+  int con_leaf[NCS];      // last dof of the contact's chain
+  int jP, jLp, jnact;     // wave-uniform: lanes per contact (4 / 2 / 1), ids per piece (12 / 20 / 36), contacts in penetration
   // per-dof registers (slot s -> dof lane + 64 s)
   float dinv[NVS];
   float qfrc_smooth[NVS], qacc_smooth[NVS];
@@ -348,7 +356,7 @@ struct Wave {
     s_cdof = l + d.o_cdof; s_cvel = l + d.o_cvel; s_qM = l + d.o_qM; s_qLD = l + d.o_qLD;
     s_cacc = s_qLD; s_cfrc = s_qLD + 6 * d.nbody; s_sc = s_qLD; s_buf = s_xpos;
     s_vec = l + d.o_vec; s_x = l + d.o_x; s_arm = l + d.o_arm; s_warm = l + d.o_warm; s_qact = l + d.o_qact;
-    s_base = (int*)(l + d.o_base);
+    s_base = (int*)(l + d.o_base); s_jlist = (int*)(l + d.o_jlist);
   }
 
   // One wavefront owns the environment: its LDS instructions execute in program order, so a
@@ -360,8 +368,6 @@ struct Wave {
   __device__ __forceinline__ v3 get_com(int r) const {
     return mk3(r ? com1[0] : com0[0], r ? com1[1] : com0[1], r ? com1[2] : com0[2]);
   }
-  // p-th ancestor dof (leaf first) of contact slot cs; p is a compile-time constant after unrolling
-  __device__ __forceinline__ int chain_at(int cs, int p) const { return (opaque(con_chain[cs][p >> 2]) >> (8 * (p & 3))) & 255; }
   // wave-uniform predicate -> scalar branch
   static __device__ __forceinline__ bool uni(bool p) { return __builtin_amdgcn_readfirstlane((int)p) != 0; }
 
@@ -1105,39 +1111,99 @@ struct Wave {
     }
   }
 
+  // J * vec is needed only for the contacts in penetration (typically 5-15 of ncon), each a walk of up to 36 dofs along
+  // the ancestor chain of its body -- with one lane per contact most lanes idle through 36 dependent LDS rounds.  Once
+  // per substep the chains of the contacts in penetration are cut into pieces of 12 / 20 / 36 dofs, 4 / 2 / 1 lanes per
+  // contact (as many as fit 64 * NCS lanes), the lanes of a contact adjacent so that a quad DPP add joins the pieces.
+  __device__ __forceinline__ void contact_jobs() {
+    int n_act = 0;
+#pragma unroll
+    for (int cs = 0; cs < NCS; ++cs) {
+      const unsigned long long m = __ballot(con_act[cs]);
+      con_rank[cs] = n_act + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+      n_act += __popcll(m);
+    }
+    jnact = n_act;
+    jP = 4 * n_act <= RR_LANES * NCS ? 4 : (2 * n_act <= RR_LANES * NCS ? 2 : 1);
+    jLp = jP == 4 ? 12 : (jP == 2 ? 20 : 36);
+    const int sh = jP == 4 ? 2 : (jP == 2 ? 1 : 0);
+#pragma unroll
+    for (int cs = 0; cs < NCS; ++cs) {
+      const int c = lane + RR_LANES * cs;
+      if (con_act[cs]) s_jlist[con_rank[cs]] = c;
+      con_leaf[cs] = c < D.ncon ? (g_int(T.con_chain_rows, 9 * c) & 255) : 0;
+    }
+    sync();
+#pragma unroll
+    for (int js = 0; js < NCS; ++js) {
+      const int J = lane + RR_LANES * js, r = J >> sh, p = J & (jP - 1);
+      jn[js] = 0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) jch[js][k] = 0;
+      if (r < n_act) {
+        const int c = s_jlist[r], start = p * jLp;
+        const int left = g_int(T.con_i, 8 * c + 4) - start;
+        jn[js] = left < 0 ? 0 : (left > jLp ? jLp : left);
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+          if (4 * k < jLp) jch[js][k] = g_int(T.con_chain_rows, 9 * c + (start >> 2) + k);   // the table has a slack row
+      }
+    }
+  }
+
   // pyramid rows of J * vec for this lane's contacts, J-free: the spatial velocity of the contact body induced by `vec`
-  // (sum of cdof * vec over the ancestor chain), taken at the contact point and projected on the frame
+  // (sum of cdof * vec over the ancestor chain, by the jobs above: pieces joined by a quad DPP add, handed to the
+  // contact's lane through the dead pose cells), taken at the contact point and projected on the frame
   __device__ __forceinline__ void jac_mul(float (*out)[4], const float* vec) {
+    const int sh = jP == 4 ? 2 : (jP == 2 ? 1 : 0);
+#pragma unroll
+    for (int js = 0; js < NCS; ++js) {
+      float w[6] = {0, 0, 0, 0, 0, 0};
+      const int n = jn[js];
+#pragma unroll
+      for (int t0 = 0; t0 < 36; t0 += 4) {
+        if (t0 < jLp) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (t0 + u < n) {
+              const int dd = (opaque(jch[js][t0 >> 2]) >> (8 * u)) & 255;
+              const float xv = vec[dd];
+              const float* cd = s_cdof + 6 * dd;
+#pragma unroll
+              for (int i = 0; i < 6; ++i) w[i] += cd[i] * xv;
+            }
+          }
+        }
+      }
+      if (jP >= 2) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[i] = dpp_add(w[i], 0);
+      }
+      if (jP == 4) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[i] = dpp_add(w[i], 1);
+      }
+      const int J = lane + RR_LANES * js;
+      if ((J & (jP - 1)) == 0 && (J >> sh) < jnact) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s_buf[6 * (J >> sh) + i] = w[i];
+      }
+    }
+    sync();
 #pragma unroll
     for (int cs = 0; cs < NCS; ++cs) {
       out[cs][0] = out[cs][1] = out[cs][2] = out[cs][3] = 0.0f;
       if (con_act[cs]) {
-        float w[6] = {0, 0, 0, 0, 0, 0};
-        const int nanc = con_nanc[cs];
-#pragma unroll
-        for (int p0 = 0; p0 < 36; p0 += 4) {
-          if (__any(p0 < nanc)) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int p = p0 + u;
-              if (p < nanc) {
-                const int dd = chain_at(cs, p);
-                const float xv = vec[dd];
-                const float* cd = s_cdof + 6 * dd;
-#pragma unroll
-                for (int i = 0; i < 6; ++i) w[i] += cd[i] * xv;
-              }
-            }
-          }
-        }
+        const float* w = s_buf + 6 * con_rank[cs];
         const v3 pv = mk3(w[3], w[4], w[5]) + cross(mk3(w[0], w[1], w[2]), mk3(con_off[cs][0], con_off[cs][1], con_off[cs][2]));
-        const float jn = dot(mk3(con_fr[cs][0], con_fr[cs][1], con_fr[cs][2]), pv);
+        const float jn_ = dot(mk3(con_fr[cs][0], con_fr[cs][1], con_fr[cs][2]), pv);
         const float j1 = dot(mk3(con_fr[cs][3], con_fr[cs][4], con_fr[cs][5]), pv);
         const float j2 = dot(mk3(con_fr[cs][6], con_fr[cs][7], con_fr[cs][8]), pv);
         const float mu = con_mu[cs];
-        out[cs][0] = jn + mu * j1; out[cs][1] = jn - mu * j1; out[cs][2] = jn + mu * j2; out[cs][3] = jn - mu * j2;
+        out[cs][0] = jn_ + mu * j1; out[cs][1] = jn_ - mu * j1; out[cs][2] = jn_ + mu * j2; out[cs][3] = jn_ - mu * j2;
       }
     }
+    sync();     // the pose cells are reused (solve partial sums, line-search staging)
   }
 
   // constraint state at the current Jaref: forces, qfrc_constraint, cost  [UP mjx solver._update_constraint]
@@ -1176,7 +1242,7 @@ struct Wave {
           W[0] = tau.x; W[1] = tau.y; W[2] = tau.z; W[3] = F.x; W[4] = F.y; W[5] = F.z;
         }
       }
-      const int leaf = chain_at(cs, 0);
+      const int leaf = con_leaf[cs];
       unsigned long long mask = __ballot(has);
       while (mask) {
         const int l = __builtin_ctzll(mask);
@@ -1279,7 +1345,7 @@ struct Wave {
   __device__ __forceinline__ void linesearch() {
     float red[4] = {0, 0, 0, 0};
     put_vec(search);   // mv = M search is carried by the caller's recurrence
-    for (int rep = 0; rep < RR_REP_JAC; ++rep) jac_mul(con_jv, s_vec);
+    for (int rep = 0; rep < RR_REP_JAC; ++rep) { float t_[NCS][4]; jac_mul(t_, s_vec); asm volatile("" :: "v"(t_[0][0]), "v"(t_[0][1]), "v"(t_[0][2]), "v"(t_[0][3]) : "memory"); }
     jac_mul(con_jv, s_vec);
     stamp<PROF>(16);
 #pragma unroll
@@ -1608,13 +1674,7 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
       for (int e = lane; e < 10 * D.nbody; e += RR_LANES) dg[D.g_crb + e] = w.s_crb[e];
       for (int e = lane; e < 6 * D.nbody; e += RR_LANES) dg[D.g_cfrc + e] = w.s_cfrc[e];
     }
-    {   // contact chains: needed from here to the end of the substep
-      const int ol = opaque(lane);
-#pragma unroll
-      for (int cs = 0; cs < NCS; ++cs)
-#pragma unroll
-        for (int k = 0; k < 9; ++k) w.con_chain[cs][k] = T.con_chain_packed[k * (NCS * RR_LANES) + cs * RR_LANES + ol];
-    }
+    w.contact_jobs();     // J*x jobs of the contacts in penetration: needed from here to the end of the substep
     w.sync();
     for (int rep = 0; rep < RR_REP_MM; ++rep) w.mass_matrix();
     w.mass_matrix();

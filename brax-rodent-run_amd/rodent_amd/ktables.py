@@ -310,4 +310,11 @@ def build_kernel_tables(m):
         for p in range(int(nanc[c])):
             packed[p // 4, c] |= int(chain_tab[p, c]) << (8 * (p % 4))
     k["k_con_chain_packed"] = packed.astype(np.uint32).view(np.int32)
+    # the same chains contact-major: 9 ints (36 dof ids, leaf first) per contact, + one row of slack; the J*x jobs of the
+    # kernel (Wave::contact_jobs) read aligned pieces of 12 / 20 / 36 ids from it
+    rows9 = np.zeros((ncon + 1, 9), np.int64)
+    for c in range(ncon):
+        for p in range(int(nanc[c])):
+            rows9[c, p // 4] |= int(chain_tab[p, c]) << (8 * (p % 4))
+    k["k_con_chain_rows"] = (rows9 & 0xFFFFFFFF).astype(np.uint32).view(np.int32).reshape(-1)
     return k

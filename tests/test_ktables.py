@@ -190,3 +190,6 @@ def test_contact_chain_is_a_dfs_interval(model_and_state):
             continue
         assert chain[0] == leaf and chain == [int(x) for x in anc[anc_adr[leaf]:anc_adr[leaf + 1]][::-1]]
         assert sorted(chain) == [dd for dd in range(nv) if dd <= leaf <= last[dd]]
+        rows = m["k_con_chain_rows"].view(np.uint32).reshape(-1, 9)            # contact-major copy read by the J*x jobs
+        assert [(int(rows[c, p >> 2]) >> (8 * (p & 3))) & 255 for p in range(nanc)] == chain
+    assert m["k_con_chain_rows"].size == 9 * (ncon + 1)
