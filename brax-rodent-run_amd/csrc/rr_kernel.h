@@ -1308,12 +1308,15 @@ struct Wave {
   // line-search point(s): cost and derivatives of the piecewise-quadratic 1-D cost at alpha, over the COMPACTED active
   // rows (see linesearch): row r*64 + lane of the first R rows; padding rows are (0, 0, 0) and never active
   static constexpr int KR = 4 * NCS + NVS;     // row slots per lane if every contact / limit row were active
-  template <int NP>
+  // COST = false: derivatives only (the bracketing iterations never look at the cost; the costs of the two final points
+  // are evaluated once after the loop, at the same alphas, by the same sums -- identical values, 3 fewer wave sums / point)
+  template <int NP, bool COST>
   __device__ __forceinline__ void ls_eval(const float* alpha, const float* qg, LSPoint* out, int R, const float* rjr, const float* rjv,
                                           const float* rD) {
-    float q[3 * NP];
+    constexpr int NQ = COST ? 3 : 2;
+    float q[NQ * NP];
 #pragma unroll
-    for (int i = 0; i < 3 * NP; ++i) q[i] = 0.0f;
+    for (int i = 0; i < NQ * NP; ++i) q[i] = 0.0f;
 #pragma unroll
     for (int r = 0; r < KR; ++r) {
       if (r * RR_LANES < R) {
@@ -1321,16 +1324,16 @@ struct Wave {
         const float q0 = 0.5f * jr * jr * Dv, q1 = jv * jr * Dv, q2 = 0.5f * jv * jv * Dv;
 #pragma unroll
         for (int i = 0; i < NP; ++i)
-          if (jr + alpha[i] * jv < 0) { q[3 * i] += q0; q[3 * i + 1] += q1; q[3 * i + 2] += q2; }
+          if (jr + alpha[i] * jv < 0) { q[NQ * i] += q1; q[NQ * i + 1] += q2; if (COST) q[NQ * i + 2] += q0; }
       }
     }
-    wave_sum_n<3 * NP>(q);
+    wave_sum_n<NQ * NP>(q);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      const float q0 = qg[0] + q[3 * i], q1 = qg[1] + q[3 * i + 1], q2 = qg[2] + q[3 * i + 2];
+      const float q1 = qg[1] + q[NQ * i], q2 = qg[2] + q[NQ * i + 1];
       const float a = alpha[i];
       out[i].alpha = a;
-      out[i].cost = a * a * q2 + a * q1 + q0;
+      out[i].cost = COST ? a * a * q2 + a * q1 + (qg[0] + q[NQ * i + (COST ? 2 : 0)]) : 0.0f;
       out[i].d0 = 2.0f * a * q2 + q1;
       out[i].d1 = 2.0f * q2 + (q2 == 0.0f ? RR_MINVAL : 0.0f);
     }
@@ -1394,9 +1397,9 @@ struct Wave {
     stamp<PROF>(17);
     LSPoint p0, lo, hi, tmp3[3];
     float a1[1] = {0.0f};
-    ls_eval<1>(a1, qg, &p0, R, rjr, rjv, rD);
+    ls_eval<1, true>(a1, qg, &p0, R, rjr, rjv, rD);
     a1[0] = p0.alpha - p0.d0 / p0.d1;
-    ls_eval<1>(a1, qg, &lo, R, rjr, rjv, rD);
+    ls_eval<1, false>(a1, qg, &lo, R, rjr, rjv, rD);
     if (lo.d0 < p0.d0) { hi = p0; } else { hi = lo; lo = p0; }
     stamp<PROF>(18);
     bool swap = true;
@@ -1406,7 +1409,7 @@ struct Wave {
       done |= (hi.d0 > 0) && (hi.d0 < gtol);
       if (uni(done)) break;
       const float a3[3] = {lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, 0.5f * (lo.alpha + hi.alpha)};
-      ls_eval<3>(a3, qg, tmp3, R, rjr, rjv, rD);
+      ls_eval<3, false>(a3, qg, tmp3, R, rjr, rjv, rD);
       const LSPoint lo_next = tmp3[0], hi_next = tmp3[1], mid = tmp3[2];
       const bool swap_lo_next = (lo.d0 > 0) || (lo.d0 < lo_next.d0);
       if (swap_lo_next) lo = lo_next;
@@ -1417,6 +1420,12 @@ struct Wave {
       const bool swap_hi_mid = (mid.d0 > 0) && (hi.d0 > mid.d0);
       if (swap_hi_mid) hi = mid;
       swap = swap_lo_next || swap_lo_mid || swap_hi_next || swap_hi_mid;
+    }
+    {   // costs of the bracket's end points
+      const float a2[2] = {lo.alpha, hi.alpha};
+      LSPoint f2[2];
+      ls_eval<2, true>(a2, qg, f2, R, rjr, rjv, rD);
+      lo.cost = f2[0].cost; hi.cost = f2[1].cost;
     }
     stamp<PROF>(19);
     const bool improved = uni((lo.cost < p0.cost) || (hi.cost < p0.cost));
