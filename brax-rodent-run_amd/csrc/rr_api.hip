@@ -45,7 +45,7 @@ static void layout(rr_model* m) {
   const RRLayout L = rr_layout(d.nq, d.nv, d.nu, d.nbody, d.nM, d.ncon);
   k.o_qpos = L.o_qpos; k.o_qvel = L.o_qvel; k.o_act = L.o_act; k.o_ctrl = L.o_ctrl; k.o_xpos = L.o_xpos; k.o_xquat = L.o_xquat;
   k.o_cinert = L.o_cinert; k.o_cdof = L.o_cdof; k.o_cvel = L.o_cvel; k.o_qM = L.o_qM; k.o_qLD = L.o_qLD; k.o_vec = L.o_vec; k.o_x = L.o_x;
-  k.o_arm = L.o_arm; k.o_warm = L.o_warm; k.o_qact = L.o_qact; k.o_base = L.o_base; k.o_jlist = L.o_jlist; k.lds_floats = L.lds_floats;
+  k.o_arm = L.o_arm; k.o_warm = L.o_warm; k.o_qact = L.o_qact; k.o_jlist = L.o_jlist; k.lds_floats = L.lds_floats;
   const int o = L.lds_floats;
   // staging of the line search's compacted rows: cinert | cvel | pose regions each hold 4*ncon + nv floats
   m->stage_ok = 6 * d.ncon <= std::max(7 * d.nbody + 4, 6 * d.nv) && 4 * d.ncon + d.nv <= std::min(std::min(10 * d.nbody, 6 * d.nbody), std::max(7 * d.nbody + 4, 6 * d.nv));
@@ -98,8 +98,8 @@ extern "C" int rr_model_load(const char* path, rr_model** out) {
   }
   static const char* need[] = {"nq", "nv", "nu", "nbody", "njnt", "ngeom", "nM", "ncon", "nlimit", "nefc", "obs_dim", "k_slots",
                                "k_body_i", "k_body_f", "k_jnt_i", "k_jnt_f", "k_dof_i", "k_dof_f", "k_act_f", "k_M_ij_k", "k_body_anc",
-                               "k_nround", "k_factor3", "k_factor3_rows", "k_linv", "k_linv_rows", "k_coljob", "k_rowjob", "k_rowjob_chain",
-                               "k_jobown", "k_solve_lmax", "k_dof_base", "k_con_i", "k_con_f", "k_con_chain_packed", "k_con_chain_rows", "k_root_mass",
+                               "k_nround", "k_factor3", "k_factor3_rows", "k_linv", "k_linv_rows", "k_coljob", "k_rowjob",
+                               "k_jobown", "k_solve_lmax", "k_con_i", "k_con_f", "k_con_chain_packed", "k_con_chain_rows", "k_root_mass",
                                "dof_depth", "body_depth", "opt_timestep", "opt_gravity", "stat_meaninertia"};
   for (const char* nme : need)
     if (!m->find(nme)) { std::string s = std::string("rr_model_load: blob lacks '") + nme + "'"; delete m; return fail(RR_EIO, s); }
@@ -124,7 +124,8 @@ extern "C" int rr_model_load(const char* path, rr_model** out) {
   if (d.nM > RR_LANES * (m->NVS == 1 ? 10 : (m->NVS == 2 ? 18 : 35))) { delete m; return fail(RR_EUNSUPPORTED, "rr_model_load: more mass-matrix entries than the kernel's register table"); }
   k.nfac = m->iscalar("k_factor3_rows");
   { const int njs = (m->NVS >= 3 ? m->NVS + 1 : m->NVS) * RR_LANES;     // Wave::NJS job slots
-    if ((int)m->find("k_coljob")->count != njs || (int)m->find("k_rowjob")->count != njs || m->iscalar("k_solve_lmax") > 16) {
+    k.lmax = m->iscalar("k_solve_lmax");
+    if ((int)m->find("k_coljob")->count != 9 * njs || (int)m->find("k_rowjob")->count != 5 * njs || k.lmax > 16 || k.lmax < 1) {
       delete m; return fail(RR_EIO, "rr_model_load: solve job tables do not match the kernel instance (stale blob)"); } }
   k.obs_dim = d.obs_dim; k.iterations = d.iterations; k.ls_iterations = d.ls_iterations;
   k.dt = d.timestep; k.gx = m->fscalar("opt_gravity", 0); k.gy = m->fscalar("opt_gravity", 1); k.gz = m->fscalar("opt_gravity", 2);
@@ -230,7 +231,7 @@ extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t devi
   int rc = 0;
 #define UP(field, name) if ((rc = upload(b, name, &b->T.field))) { rr_batch_destroy(b); return rc; }
   UP(body_i, "k_body_i") UP(jnt_i, "k_jnt_i") UP(dof_i, "k_dof_i") UP(M_ij_k, "k_M_ij_k")
-  UP(body_anc, "k_body_anc") UP(con_chain_rows, "k_con_chain_rows") UP(coljob, "k_coljob") UP(rowjob, "k_rowjob") UP(rowjob_chain, "k_rowjob_chain") UP(jobown, "k_jobown") UP(dof_base, "k_dof_base") UP(con_i, "k_con_i")
+  UP(body_anc, "k_body_anc") UP(con_chain_rows, "k_con_chain_rows") UP(coljob, "k_coljob") UP(rowjob, "k_rowjob") UP(jobown, "k_jobown") UP(con_i, "k_con_i")
   UP(body_f, "k_body_f") UP(jnt_f, "k_jnt_f") UP(dof_f, "k_dof_f")
   UP(act_f, "k_act_f") UP(con_f, "k_con_f") UP(root_mass, "k_root_mass")
 #undef UP

@@ -28,11 +28,11 @@
 
 struct RRDims {
   int nq, nv, nu, nbody, njnt, nM, ncon, dmax, nroot;
-  int obs_dim, iterations, ls_iterations, nfac, nround, ninv;
+  int obs_dim, iterations, ls_iterations, nfac, nround, ninv, lmax;
   float dt, gx, gy, gz, tolerance, ls_tolerance, meaninertia;
   // LDS offsets (floats)
   int o_qpos, o_qvel, o_act, o_ctrl, o_xpos, o_xquat, o_cinert, o_cdof, o_cvel,
-      o_qM, o_qLD, o_vec, o_x, o_arm, o_warm, o_qact, o_base, o_jlist, lds_floats;
+      o_qM, o_qLD, o_vec, o_x, o_arm, o_warm, o_qact, o_jlist, lds_floats;
   // debug dump offsets (floats)
   int g_xpos, g_xquat, g_xmat, g_com, g_cinert, g_crb, g_cdof, g_cvel, g_cfrc, g_qM, g_qLD, g_dinv, g_bias, g_passive,
       g_actuator, g_smooth, g_qacc_smooth, g_con_dist, g_con_pos, g_con_frame, g_con_D, g_con_aref, g_lim, g_qacc,
@@ -42,7 +42,7 @@ struct RRDims {
 // LDS layout of one environment (float offsets).  One constexpr function serves the host (rr_api.hip layout) and the
 // kernel instance compiled for fixed model dimensions.
 struct RRLayout {
-  int o_qpos, o_qvel, o_act, o_ctrl, o_xpos, o_xquat, o_cinert, o_cdof, o_cvel, o_qM, o_qLD, o_vec, o_x, o_arm, o_warm, o_qact, o_base, o_jlist, lds_floats;
+  int o_qpos, o_qvel, o_act, o_ctrl, o_xpos, o_xquat, o_cinert, o_cdof, o_cvel, o_qM, o_qLD, o_vec, o_x, o_arm, o_warm, o_qact, o_jlist, lds_floats;
 };
 constexpr int rr_imax(int a, int b) { return a > b ? a : b; }
 constexpr int rr_up4(int n) { return (n + 3) & ~3; }
@@ -59,14 +59,13 @@ constexpr RRLayout rr_layout(int nq, int nv, int nu, int nbody, int nM, int ncon
   k.o_cinert = o; o += rr_up4(10 * nbody);      // composite inertia accumulates in place
   k.o_cdof = o; o += rr_up4(6 * nv);
   k.o_cvel = o; o += rr_up4(6 * nbody);
-  k.o_qM = o; o += rr_up4(nM);
-  k.o_qLD = o; o += rr_up4(rr_imax(rr_imax(nM + 4, 12 * nbody), 2 * nv));   // also cacc | cfrc and the sin/cos scratch
-  k.o_vec = o; o += rr_up4(nv);
-  k.o_x = o; o += rr_up4(nv);
+  k.o_qM = o; o += rr_up4(nM + 16);          // + cells that hold 0: the job descriptors pad with cell nM, padded row steps read on
+  k.o_qLD = o; o += rr_up4(rr_imax(rr_imax(nM + 20, 12 * nbody), 2 * nv));   // also cacc | cfrc and the sin/cos scratch
+  k.o_vec = o; o += rr_up4(nv + 16);         // vector cells nv.. hold 0 (padding of the job descriptors; padded column steps read on)
+  k.o_x = o; o += rr_up4(nv + 16);
   k.o_arm = o; o += rr_up4(2 * nv);
   k.o_warm = o; o += rr_up4(nv);
   k.o_qact = o; o += rr_up4(nv);
-  k.o_base = o; o += rr_up4(nv);
   k.o_jlist = o; o += rr_up4(ncon);      // ids of the contacts in penetration, by rank (J*x jobs)
   k.lds_floats = o;
   return k;
@@ -77,20 +76,20 @@ constexpr RRLayout rr_layout(int nq, int nv, int nu, int nbody, int nM, int ncon
 // spills hundreds of SGPRs to VGPR lanes).  Members of the same name hide the run-time fields of RRDims; everything else
 // (solver options, table row counts, debug offsets) stays run-time.  The host selects it only when every constant matches.
 struct RRDimsRodent : RRDims {
-  static constexpr int nq = 74, nv = 73, nu = 30, nbody = 66, njnt = 68, nM = 1119, ncon = 59, dmax = 35, nroot = 1, obs_dim = 1263, nround = 6;
+  static constexpr int nq = 74, nv = 73, nu = 30, nbody = 66, njnt = 68, nM = 1119, ncon = 59, dmax = 35, nroot = 1, obs_dim = 1263, nround = 6, lmax = 12;
   static constexpr RRLayout LY = rr_layout(nq, nv, nu, nbody, nM, ncon);
   static constexpr int o_qpos = LY.o_qpos, o_qvel = LY.o_qvel, o_act = LY.o_act, o_ctrl = LY.o_ctrl, o_xpos = LY.o_xpos, o_xquat = LY.o_xquat,
                        o_cinert = LY.o_cinert, o_cdof = LY.o_cdof, o_cvel = LY.o_cvel, o_qM = LY.o_qM, o_qLD = LY.o_qLD, o_vec = LY.o_vec,
-                       o_x = LY.o_x, o_arm = LY.o_arm, o_warm = LY.o_warm, o_qact = LY.o_qact, o_base = LY.o_base, o_jlist = LY.o_jlist,
+                       o_x = LY.o_x, o_arm = LY.o_arm, o_warm = LY.o_warm, o_qact = LY.o_qact, o_jlist = LY.o_jlist,
                        lds_floats = LY.lds_floats;
   __host__ __device__ RRDimsRodent(const RRDims& d) : RRDims(d) {}
   static bool matches(const RRDims& d) {
     const RRDims& r = d;
     return r.nq == nq && r.nv == nv && r.nu == nu && r.nbody == nbody && r.njnt == njnt && r.nM == nM && r.ncon == ncon && r.dmax == dmax &&
-           r.nroot == nroot && r.obs_dim == obs_dim && r.nround == nround && r.o_qpos == o_qpos && r.o_qvel == o_qvel && r.o_act == o_act &&
+           r.nroot == nroot && r.obs_dim == obs_dim && r.nround == nround && r.lmax == lmax && r.o_qpos == o_qpos && r.o_qvel == o_qvel && r.o_act == o_act &&
            r.o_ctrl == o_ctrl && r.o_xpos == o_xpos && r.o_xquat == o_xquat && r.o_cinert == o_cinert && r.o_cdof == o_cdof &&
            r.o_cvel == o_cvel && r.o_qM == o_qM && r.o_qLD == o_qLD && r.o_vec == o_vec && r.o_x == o_x && r.o_arm == o_arm &&
-           r.o_warm == o_warm && r.o_qact == o_qact && r.o_base == o_base && r.o_jlist == o_jlist && r.lds_floats == lds_floats;
+           r.o_warm == o_warm && r.o_qact == o_qact && r.o_jlist == o_jlist && r.lds_floats == lds_floats;
   }
 };
 
@@ -98,7 +97,7 @@ struct RRDimsRodent : RRDims {
 typedef const int __attribute__((address_space(1)))* rr_gi;
 typedef const float __attribute__((address_space(1)))* rr_gf;
 struct RRTables {
-  rr_gi factor3, linv, coljob, rowjob, rowjob_chain, jobown, dof_base, body_i, jnt_i, dof_i, M_ij_k, body_anc, con_chain_rows, con_i;
+  rr_gi factor3, linv, coljob, rowjob, jobown, body_i, jnt_i, dof_i, M_ij_k, body_anc, con_chain_rows, con_i;
   rr_gf body_f, jnt_f, dof_f, act_f, con_f, root_mass;
 };
 
@@ -313,7 +312,6 @@ struct Wave {
   float *s_qpos, *s_qvel, *s_act, *s_ctrl, *s_xpos, *s_xquat, *s_cinert, *s_crb, *s_cdof, *s_cvel, *s_cacc,
       *s_cfrc, *s_buf, *s_sc, *s_qM, *s_qLD, *s_vec, *s_x, *s_arm, *s_warm, *s_qact;
   int* s_jlist;           // contact ids by rank (J*x jobs)
-  int* s_base;            // Madr + depth per dof (entry (i, j) of a descendant i of j sits at s_base[i] - depth[j])
 
   static constexpr int W = NVS * RR_LANES;
   static constexpr int WC = NCS * RR_LANES;
@@ -356,7 +354,7 @@ struct Wave {
     s_cdof = l + d.o_cdof; s_cvel = l + d.o_cvel; s_qM = l + d.o_qM; s_qLD = l + d.o_qLD;
     s_cacc = s_qLD; s_cfrc = s_qLD + 6 * d.nbody; s_sc = s_qLD; s_buf = s_xpos;
     s_vec = l + d.o_vec; s_x = l + d.o_x; s_arm = l + d.o_arm; s_warm = l + d.o_warm; s_qact = l + d.o_qact;
-    s_base = (int*)(l + d.o_base); s_jlist = (int*)(l + d.o_jlist);
+    s_jlist = (int*)(l + d.o_jlist);
   }
 
   // One wavefront owns the environment: its LDS instructions execute in program order, so a
@@ -843,65 +841,70 @@ struct Wave {
   // D.lmax (<= 16) entries, one piece per lane and job slot (k_coljob / k_rowjob); the piece sums go through the (dead)
   // pose cells s_buf and the owner lane of the column / row adds up its pieces.  Lane d owns x_d.
   static constexpr int NJS = NVS >= 3 ? NVS + 1 : NVS;      // job slots per lane (ktables: nslot)
-  // this lane's jobs, reloaded per call from the L2-resident tables (held across the solver they would be spilled)
-  __device__ __forceinline__ void load_jobs(int* cj, int* rj, int (*rch)[4], int* own) {
+  // This lane's jobs (rodent_amd/ktables.py), reloaded per call from the L2-resident tables (held across the solver they
+  // would be spilled).  PREDICATE-FREE: every job runs D.lmax steps; a column job lists the byte offsets of its matrix
+  // entries (padding: the matrix array's ZERO cell) and walks the vector from i0, a row job lists its ancestor dof ids
+  // (padding: vector cell nv, which always holds 0) and walks the matrix row from byte offset ra.
+  struct Jobs { int cw[NJS][8], ci0[NJS], rb[NJS][4], ra[NJS], own[NVS]; };
+  __device__ __forceinline__ void load_jobs(Jobs& j) {
     constexpr int WJ = NJS * RR_LANES;
     const int ol = opaque(lane);
 #pragma unroll
     for (int s = 0; s < NJS; ++s) {
-      cj[s] = g_int(T.coljob, s * RR_LANES + ol);
-      rj[s] = g_int(T.rowjob, s * RR_LANES + ol);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) rch[s][k] = g_int(T.rowjob_chain, k * WJ + s * RR_LANES + ol);
+      for (int k = 0; k < 8; ++k) j.cw[s][k] = 2 * k < D.lmax ? g_int(T.coljob, k * WJ + s * RR_LANES + ol) : 0;
+      j.ci0[s] = g_int(T.coljob, 8 * WJ + s * RR_LANES + ol);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) j.rb[s][k] = 4 * k < D.lmax ? g_int(T.rowjob, k * WJ + s * RR_LANES + ol) : 0;
+      j.ra[s] = g_int(T.rowjob, 4 * WJ + s * RR_LANES + ol);
     }
 #pragma unroll
-    for (int s = 0; s < NVS; ++s) own[s] = ol + RR_LANES * s < D.nv ? g_int(T.jobown, ol + RR_LANES * s) : 0;
+    for (int s = 0; s < NVS; ++s) j.own[s] = ol + RR_LANES * s < D.nv ? g_int(T.jobown, ol + RR_LANES * s) : 0;
+  }
+  // column piece: sum_t mat[cw_t] * vec[i0 + t];  row piece: sum_t mat[ra + t] * vec[rb_t]   (mat = s_qLD or s_qM)
+  __device__ __forceinline__ float col_piece(const Jobs& j, int s, const float* mat, const float* vec) const {
+    const float* v = vec + j.ci0[s];
+    float acc = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+      if (t < D.lmax) acc += *(const float*)((const char*)mat + ((j.cw[s][t >> 1] >> (16 * (t & 1))) & 0xFFFF)) * v[t];
+    return acc;
+  }
+  __device__ __forceinline__ float row_piece(const Jobs& j, int s, const float* mat, const float* vec) const {
+    const float* m_ = (const float*)((const char*)mat + j.ra[s]);
+    float acc = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+      if (t < D.lmax) acc += m_[t] * vec[(j.rb[s][t >> 2] >> (8 * (t & 3))) & 255];
+    return acc;
   }
   __device__ __forceinline__ void ldl_solve(float* x) {
-    int cj[NJS], rj[NJS], rch[NJS][4], own[NVS];
-    load_jobs(cj, rj, rch, own);
+    Jobs jb;
+    load_jobs(jb);
 #pragma unroll
     for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; if (d < D.nv) s_x[d] = x[s]; }
     sync();
 #pragma unroll
-    for (int s = 0; s < NJS; ++s) {
-      const int i0 = (cj[s] >> 8) & 255, n = (cj[s] >> 16) & 255, dj = (int)((unsigned)cj[s] >> 24);
-      float acc = 0.0f;
-#pragma unroll 4
-      for (int t = 0; t < n; ++t) acc += s_qLD[s_base[i0 + t] - dj] * s_x[i0 + t];
-      s_buf[s * RR_LANES + lane] = acc;
-    }
+    for (int s = 0; s < NJS; ++s) s_buf[s * RR_LANES + lane] = col_piece(jb, s, s_qLD, s_x);
     sync();
     float y[NVS];
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
-      const int t0 = own[s] & 255, c = (own[s] >> 8) & 255;
+      const int t0 = jb.own[s] & 255, c = (jb.own[s] >> 8) & 255;
       float sum = 0.0f;
       for (int r = 0; r < c; ++r) sum += s_buf[t0 + r];
       y[s] = (x[s] - sum) * dinv[s];
     }
-    sync();
+    // every lane has taken its column pieces of x (hand-off above): the vector cells can take y
 #pragma unroll
     for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; if (d < D.nv) s_x[d] = y[s]; }
     sync();
 #pragma unroll
-    for (int s = 0; s < NJS; ++s) {
-      const int adr0 = rj[s] & 4095, n = rj[s] >> 12;
-      float acc = 0.0f;
-#pragma unroll
-      for (int t0 = 0; t0 < 16; t0 += 4) {
-        if (__any(t0 < n)) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (t0 + u < n) acc += s_qLD[adr0 + t0 + u] * s_x[(rch[s][t0 >> 2] >> (8 * u)) & 255];
-        }
-      }
-      s_buf[s * RR_LANES + lane] = acc;
-    }
+    for (int s = 0; s < NJS; ++s) s_buf[s * RR_LANES + lane] = row_piece(jb, s, s_qLD, s_x);
     sync();
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
-      const int t0 = (own[s] >> 16) & 255, c = (int)((unsigned)own[s] >> 24);
+      const int t0 = (jb.own[s] >> 16) & 255, c = (int)((unsigned)jb.own[s] >> 24);
       float sum = 0.0f;
       for (int r = 0; r < c; ++r) sum += s_buf[t0 + r];
       x[s] = y[s] - sum;
@@ -914,26 +917,12 @@ struct Wave {
   // the same balanced jobs (k_coljob / k_rowjob), on s_qM.  No atomics.
   __device__ __forceinline__ void mul_m(float* y) {
     constexpr int WJ = NJS * RR_LANES;
-    int cj[NJS], rj[NJS], rch[NJS][4], own[NVS];
-    load_jobs(cj, rj, rch, own);
+    Jobs jb;
+    load_jobs(jb);
 #pragma unroll
     for (int s = 0; s < NJS; ++s) {
-      const int i0 = (cj[s] >> 8) & 255, n = (cj[s] >> 16) & 255, dj = (int)((unsigned)cj[s] >> 24);
-      float acc = 0.0f;
-#pragma unroll 4
-      for (int t = 0; t < n; ++t) acc += s_qM[s_base[i0 + t] - dj] * s_vec[i0 + t];
-      s_buf[s * RR_LANES + lane] = acc;
-      const int adr0 = rj[s] & 4095, nr = rj[s] >> 12;
-      acc = 0.0f;
-#pragma unroll
-      for (int t0 = 0; t0 < 16; t0 += 4) {
-        if (__any(t0 < nr)) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (t0 + u < nr) acc += s_qM[adr0 + t0 + u] * s_vec[(rch[s][t0 >> 2] >> (8 * u)) & 255];
-        }
-      }
-      s_buf[WJ + s * RR_LANES + lane] = acc;
+      s_buf[s * RR_LANES + lane] = col_piece(jb, s, s_qM, s_vec);
+      s_buf[WJ + s * RR_LANES + lane] = row_piece(jb, s, s_qM, s_vec);
     }
     sync();
 #pragma unroll
@@ -942,7 +931,7 @@ struct Wave {
       float sum = 0.0f;
       if (d < D.nv) {
         sum = s_qM[opaque(dofc1[s]) & 0xFFFF] * s_vec[d];
-        const int t0 = own[s] & 255, c = (own[s] >> 8) & 255, r0 = (own[s] >> 16) & 255, cr = (int)((unsigned)own[s] >> 24);
+        const int t0 = jb.own[s] & 255, c = (jb.own[s] >> 8) & 255, r0 = (jb.own[s] >> 16) & 255, cr = (int)((unsigned)jb.own[s] >> 24);
         for (int r = 0; r < c; ++r) sum += s_buf[t0 + r];
         for (int r = 0; r < cr; ++r) sum += s_buf[WJ + r0 + r];
       }
@@ -1599,7 +1588,8 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
     }
     w.qacc[s] = w.Ma[s] = w.grad[s] = w.Mgrad[s] = w.search[s] = w.mv[s] = w.qfrc_con[s] = 0.0f;
   }
-  for (int i = lane; i < D.nv; i += RR_LANES) { w.s_arm[i] = T.dof_f[16 * i]; w.s_base[i] = T.dof_base[i]; }
+  for (int i = lane; i < D.nv; i += RR_LANES) w.s_arm[i] = T.dof_f[16 * i];
+  if (lane < 16) { w.s_qM[D.nM + lane] = 0.0f; w.s_qLD[D.nM + 4 + lane] = 0.0f; w.s_vec[D.nv + lane] = 0.0f; w.s_x[D.nv + lane] = 0.0f; }   // zero cells the job descriptors pad with / padded steps read
   w.sync();
 
   if (PROF) { for (int i = 0; i < RR_NPH; ++i) w.pt[i] = 0; w.pt_last = __builtin_readcyclecounter(); }

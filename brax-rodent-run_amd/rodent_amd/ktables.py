@@ -138,7 +138,7 @@ def build_kernel_tables(m):
     dmax = int(ddepth.max())
     Wd = NVS * LANES
     by_level = [[i for i in range(nv) if ddepth[i] == l] for l in range(dmax + 1)]
-    if nM >= 4095:
+    if nM >= 4090 or nv >= 255:
         raise ValueError("nM above the 12-bit address field of the solve job tables")
 
     # ---- atomic-free factorisation and inversion schedules.  Both are lists of LEVELS; a level is a list of table rows
@@ -226,7 +226,6 @@ def build_kernel_tables(m):
                 ops += quads(mk, int(Madr[kk] + 1), mk + 1, l, 0)
         levels.append([(ops[r0:r0 + LANES], 1) for r0 in range(0, len(ops), LANES)])
     k["k_linv"], k["k_linv_rows"] = pack_levels(levels)
-    k["k_dof_base"] = (Madr[:nv] + ddepth[:nv]).astype(np.int32)   # entry (i, j) of a descendant i sits at base[i] - depth[j]
 
     # ---- balanced jobs of the two sparse products of the solve (Wave::ldl_solve).  Column product (U' b): column j sums
     # over its descendants i = j+1 .. last_desc[j]; row product (U y): row i sums over its ancestors p = 1 .. depth[i].  Both
@@ -242,9 +241,16 @@ def build_kernel_tables(m):
         lmax += 1
     if lmax > 16:
         raise ValueError("solve jobs longer than 16 entries")
-    coljob = np.zeros(nslot, np.int64)          # j | i0 << 8 | n << 16 | depth[j] << 24   (n = 0: no job)
-    rowjob = np.zeros(nslot, np.int64)          # Madr[i] + p0 | n << 12
-    rowch = np.zeros((4, nslot), np.int64)      # ancestor dof ids of the piece, 4 per int
+    # Predicate-free job descriptors (the kernel runs every job for lmax steps): a column job lists the byte offsets
+    # 4 * (base[i] - depth[j]) of its matrix entries, 2 per int, padded with the ZERO cell 4 * nM, and walks the vector from
+    # i0; a row job lists its ancestor dof ids, 4 per int, padded with nv (a vector cell that always holds 0), and walks
+    # the matrix row from byte offset 4 * (Madr[i] + p0).
+    coljob = np.zeros((9, nslot), np.int64)     # [0..7]: byte offsets (16 bits each), [8]: i0
+    rowjob = np.zeros((5, nslot), np.int64)     # [0..3]: ancestor ids (8 bits each), [4]: byte offset of the first entry
+    for t in range(nslot):
+        for u in range(16):
+            coljob[u >> 1, t] |= (4 * nM) << (16 * (u & 1))
+            rowjob[u >> 2, t] |= nv << (8 * (u & 3))
     own = np.zeros(nv, np.int64)                # first column job | count << 8 | first row job << 16 | count << 24
     t = 0
     for j in range(nv):
@@ -254,7 +260,10 @@ def build_kernel_tables(m):
         for r in range(c):
             i0 = j + 1 + r * n // c
             i1 = j + 1 + (r + 1) * n // c
-            coljob[t] = j | (i0 << 8) | ((i1 - i0) << 16) | (int(ddepth[j]) << 24)
+            coljob[8, t] = i0
+            for u, i in enumerate(range(i0, i1)):
+                coljob[u >> 1, t] &= ~(0xFFFF << (16 * (u & 1)))
+                coljob[u >> 1, t] |= (4 * int(Madr[i] + ddepth[i] - ddepth[j])) << (16 * (u & 1))
             t += 1
     t = 0
     for i in range(nv):
@@ -265,14 +274,14 @@ def build_kernel_tables(m):
         for r in range(c):
             p0 = 1 + r * n // c
             p1 = 1 + (r + 1) * n // c
-            rowjob[t] = int(Madr[i] + p0) | ((p1 - p0) << 12)
+            rowjob[4, t] = 4 * int(Madr[i] + p0)
             for u, pp in enumerate(range(p0, p1)):
-                rowch[u >> 2, t] |= int(chain[pp]) << (8 * (u & 3))
+                rowjob[u >> 2, t] &= ~(0xFF << (8 * (u & 3)))
+                rowjob[u >> 2, t] |= int(chain[pp]) << (8 * (u & 3))
             t += 1
     k["k_solve_lmax"] = np.int32(lmax)
     k["k_coljob"] = (coljob & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
-    k["k_rowjob"] = rowjob.astype(np.int32)
-    k["k_rowjob_chain"] = (rowch & 0xFFFFFFFF).astype(np.uint32).view(np.int32).reshape(4, nslot)
+    k["k_rowjob"] = (rowjob & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
     k["k_jobown"] = (own & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
 
     # ---- contacts

@@ -31,6 +31,36 @@ def model_and_state(request, oracle_built):
     return m, M, d
 
 
+def run_jobs(m, mat, vec, sign):
+    """numpy restatement of the job loops shared by Wave::ldl_solve and Wave::mul_m: every lane-slot runs its column job and
+    its row job for lmax steps without predicates (padding = the matrix array's ZERO cell / the vector's zero cell);
+    returns, per dof, the sums of its column pieces and of its row pieces.  `mat` carries nM entries + zero cell(s)."""
+    nv, nM = int(m["nv"]), int(m["nM"])
+    lmax = int(m["k_solve_lmax"])
+    cj, rj, own = m["k_coljob"].view(np.uint32).astype(np.int64), m["k_rowjob"].view(np.uint32).astype(np.int64), m["k_jobown"].view(np.uint32).astype(np.int64)
+    assert mat[nM] == 0.0
+    x = np.concatenate([vec, [0.0]])                       # vector cell nv always holds 0
+    xpad = np.concatenate([vec, np.full(32, 1e30)])        # what a padded column step may read: anything finite
+    matpad = np.concatenate([mat, np.full(32, 1e30)])
+    nslot = cj.shape[1]
+    pc, pr = np.zeros(nslot), np.zeros(nslot)
+    for t in range(nslot):
+        i0, adr0 = int(cj[8, t]), int(rj[4, t])
+        assert adr0 % 4 == 0
+        for u in range(lmax):
+            off = int(cj[u >> 1, t] >> (16 * (u & 1))) & 0xFFFF
+            assert off % 4 == 0 and off // 4 <= nM
+            pc[t] += mat[off // 4] * xpad[i0 + u]
+            a = int(rj[u >> 2, t] >> (8 * (u & 3))) & 255
+            assert a <= nv
+            pr[t] += matpad[adr0 // 4 + u] * x[a]
+        for u in range(lmax, 16):                            # beyond lmax the descriptors are padding
+            assert (int(cj[u >> 1, t] >> (16 * (u & 1))) & 0xFFFF) == 4 * nM and (int(rj[u >> 2, t] >> (8 * (u & 3))) & 255) == nv
+    col = np.array([pc[int(o & 255):int(o & 255) + int((o >> 8) & 255)].sum() for o in own])
+    row = np.array([pr[int((o >> 16) & 255):int((o >> 16) & 255) + int(o >> 24)].sum() for o in own])
+    return sign * col, sign * row
+
+
 def test_mulm_by_solve_jobs(model_and_state):
     """numpy restatement of Wave::mul_m: y = M x from the balanced column / row jobs of the solve, on qM."""
     m, M, d = model_and_state
@@ -38,19 +68,9 @@ def test_mulm_by_solve_jobs(model_and_state):
     qM = d.get("qM")
     Md = dense_from_sparse(m, qM)
     x = np.random.default_rng(1).normal(size=nv)
-    base, Madr = m["k_dof_base"], m["k_dof_i"][:, 4]
-    cj, rj, rch, own = m["k_coljob"].view(np.uint32), m["k_rowjob"], m["k_rowjob_chain"].view(np.uint32), m["k_jobown"].view(np.uint32)
-    pc, pr = np.zeros(len(cj)), np.zeros(len(rj))
-    for t, e in enumerate(cj):
-        j, i0, n, dj = int(e & 255), int((e >> 8) & 255), int((e >> 16) & 255), int(e >> 24)
-        assert n == 0 or dj == m["k_dof_i"][j, 3]
-        pc[t] = sum(qM[base[i] - dj] * x[i] for i in range(i0, i0 + n))
-    for t, e in enumerate(rj):
-        adr0, n = int(e & 4095), int(e >> 12)
-        pr[t] = sum(qM[adr0 + u] * x[(int(rch[u >> 2, t]) >> (8 * (u & 3))) & 255] for u in range(n))
-    y = np.array([qM[Madr[i]] * x[i] + pc[int(own[i] & 255):int(own[i] & 255) + int((own[i] >> 8) & 255)].sum() +
-                  pr[int((own[i] >> 16) & 255):int((own[i] >> 16) & 255) + int(own[i] >> 24)].sum() for i in range(nv)])
-    np.testing.assert_allclose(y, Md @ x, rtol=1e-12, atol=1e-14)
+    Madr = m["k_dof_i"][:, 4]
+    col, row = run_jobs(m, np.concatenate([qM, [0.0]]), x, 1.0)
+    np.testing.assert_allclose(qM[Madr] * x + col + row, Md @ x, rtol=1e-12, atol=1e-14)
 
 
 BLK = 1         # rows per block of the level schedules (RR_BLK)
@@ -130,25 +150,12 @@ def kernel_invert(m, L):
 
 def kernel_solve(m, W, dinv, b):
     """numpy restatement of Wave::ldl_solve with the explicit inverse: x = U D^-1 U' b, U = I - W, both products cut into
-    balanced per-lane-slot jobs (k_coljob / k_rowjob) whose partial sums the owner of the column / row adds up."""
-    nv = int(m["nv"])
-    base = m["k_dof_base"]
-    cj, rj, rch, own = m["k_coljob"].view(np.uint32), m["k_rowjob"], m["k_rowjob_chain"].view(np.uint32), m["k_jobown"].view(np.uint32)
-    lmax = int(m["k_solve_lmax"])
-    part = np.zeros(len(cj))
-    for t, e in enumerate(cj):
-        j, i0, n, dj = int(e & 255), int((e >> 8) & 255), int((e >> 16) & 255), int(e >> 24)
-        assert n <= lmax
-        for i in range(i0, i0 + n):
-            part[t] += W[base[i] - dj] * b[i]
-    y = np.array([(b[j] - part[int(own[j] & 255):int(own[j] & 255) + int((own[j] >> 8) & 255)].sum()) * dinv[j] for j in range(nv)])
-    part = np.zeros(len(rj))
-    for t, e in enumerate(rj):
-        adr0, n = int(e & 4095), int(e >> 12)
-        assert n <= lmax
-        for u in range(n):
-            part[t] += W[adr0 + u] * y[(int(rch[u >> 2, t]) >> (8 * (u & 3))) & 255]
-    return np.array([y[i] - part[int((own[i] >> 16) & 255):int((own[i] >> 16) & 255) + int(own[i] >> 24)].sum() for i in range(nv)])
+    balanced per-lane-slot jobs whose partial sums the owner of the column / row adds up."""
+    Wz = np.concatenate([W, [0.0]])
+    col, _ = run_jobs(m, Wz, b, -1.0)
+    y = (b + col) * dinv
+    _, row = run_jobs(m, Wz, y, -1.0)
+    return y + row
 
 
 def test_factor_and_solve_tables(model_and_state):
