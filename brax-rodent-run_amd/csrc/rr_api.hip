@@ -99,7 +99,7 @@ extern "C" int rr_model_load(const char* path, rr_model** out) {
   static const char* need[] = {"nq", "nv", "nu", "nbody", "njnt", "ngeom", "nM", "ncon", "nlimit", "nefc", "obs_dim", "k_slots",
                                "k_body_i", "k_body_f", "k_jnt_i", "k_jnt_f", "k_dof_i", "k_dof_f", "k_act_f", "k_M_ij_k", "k_body_anc",
                                "k_nround", "k_factor3", "k_factor3_rows", "k_linv", "k_linv_rows", "k_coljob", "k_rowjob",
-                               "k_jobown", "k_solve_lmax", "k_con_i", "k_con_f", "k_con_chain_packed", "k_con_chain_rows", "k_root_mass",
+                               "k_jobown", "k_solve_lmax", "k_solve_cmax", "k_solve_rmax", "k_con_i", "k_con_f", "k_con_chain_packed", "k_con_chain_rows", "k_root_mass",
                                "dof_depth", "body_depth", "opt_timestep", "opt_gravity", "stat_meaninertia"};
   for (const char* nme : need)
     if (!m->find(nme)) { std::string s = std::string("rr_model_load: blob lacks '") + nme + "'"; delete m; return fail(RR_EIO, s); }
@@ -124,8 +124,8 @@ extern "C" int rr_model_load(const char* path, rr_model** out) {
   if (d.nM > RR_LANES * (m->NVS == 1 ? 10 : (m->NVS == 2 ? 18 : 35))) { delete m; return fail(RR_EUNSUPPORTED, "rr_model_load: more mass-matrix entries than the kernel's register table"); }
   k.nfac = m->iscalar("k_factor3_rows");
   { const int njs = (m->NVS >= 3 ? m->NVS + 1 : m->NVS) * RR_LANES;     // Wave::NJS job slots
-    k.lmax = m->iscalar("k_solve_lmax");
-    if ((int)m->find("k_coljob")->count != 9 * njs || (int)m->find("k_rowjob")->count != 5 * njs || k.lmax > 16 || k.lmax < 1) {
+    k.lmax = m->iscalar("k_solve_lmax"); k.cmax = m->iscalar("k_solve_cmax"); k.rmax = m->iscalar("k_solve_rmax");
+    if ((int)m->find("k_coljob")->count != 9 * njs || (int)m->find("k_rowjob")->count != 5 * njs || k.lmax > 16 || k.lmax < 1 || k.cmax > 8 || k.rmax > 8 || k.cmax < 1) {
       delete m; return fail(RR_EIO, "rr_model_load: solve job tables do not match the kernel instance (stale blob)"); } }
   k.obs_dim = d.obs_dim; k.iterations = d.iterations; k.ls_iterations = d.ls_iterations;
   k.dt = d.timestep; k.gx = m->fscalar("opt_gravity", 0); k.gy = m->fscalar("opt_gravity", 1); k.gz = m->fscalar("opt_gravity", 2);

@@ -28,7 +28,7 @@
 
 struct RRDims {
   int nq, nv, nu, nbody, njnt, nM, ncon, dmax, nroot;
-  int obs_dim, iterations, ls_iterations, nfac, nround, ninv, lmax;
+  int obs_dim, iterations, ls_iterations, nfac, nround, ninv, lmax, cmax, rmax;
   float dt, gx, gy, gz, tolerance, ls_tolerance, meaninertia;
   // LDS offsets (floats)
   int o_qpos, o_qvel, o_act, o_ctrl, o_xpos, o_xquat, o_cinert, o_cdof, o_cvel,
@@ -76,7 +76,7 @@ constexpr RRLayout rr_layout(int nq, int nv, int nu, int nbody, int nM, int ncon
 // spills hundreds of SGPRs to VGPR lanes).  Members of the same name hide the run-time fields of RRDims; everything else
 // (solver options, table row counts, debug offsets) stays run-time.  The host selects it only when every constant matches.
 struct RRDimsRodent : RRDims {
-  static constexpr int nq = 74, nv = 73, nu = 30, nbody = 66, njnt = 68, nM = 1119, ncon = 59, dmax = 35, nroot = 1, obs_dim = 1263, nround = 6, lmax = 12;
+  static constexpr int nq = 74, nv = 73, nu = 30, nbody = 66, njnt = 68, nM = 1119, ncon = 59, dmax = 35, nroot = 1, obs_dim = 1263, nround = 6, lmax = 12, cmax = 6, rmax = 3;
   static constexpr RRLayout LY = rr_layout(nq, nv, nu, nbody, nM, ncon);
   static constexpr int o_qpos = LY.o_qpos, o_qvel = LY.o_qvel, o_act = LY.o_act, o_ctrl = LY.o_ctrl, o_xpos = LY.o_xpos, o_xquat = LY.o_xquat,
                        o_cinert = LY.o_cinert, o_cdof = LY.o_cdof, o_cvel = LY.o_cvel, o_qM = LY.o_qM, o_qLD = LY.o_qLD, o_vec = LY.o_vec,
@@ -86,7 +86,7 @@ struct RRDimsRodent : RRDims {
   static bool matches(const RRDims& d) {
     const RRDims& r = d;
     return r.nq == nq && r.nv == nv && r.nu == nu && r.nbody == nbody && r.njnt == njnt && r.nM == nM && r.ncon == ncon && r.dmax == dmax &&
-           r.nroot == nroot && r.obs_dim == obs_dim && r.nround == nround && r.lmax == lmax && r.o_qpos == o_qpos && r.o_qvel == o_qvel && r.o_act == o_act &&
+           r.nroot == nroot && r.obs_dim == obs_dim && r.nround == nround && r.lmax == lmax && r.cmax == cmax && r.rmax == rmax && r.o_qpos == o_qpos && r.o_qvel == o_qvel && r.o_act == o_act &&
            r.o_ctrl == o_ctrl && r.o_xpos == o_xpos && r.o_xquat == o_xquat && r.o_cinert == o_cinert && r.o_cdof == o_cdof &&
            r.o_cvel == o_cvel && r.o_qM == o_qM && r.o_qLD == o_qLD && r.o_vec == o_vec && r.o_x == o_x && r.o_arm == o_arm &&
            r.o_warm == o_warm && r.o_qact == o_qact && r.o_jlist == o_jlist && r.lds_floats == lds_floats;
@@ -878,6 +878,14 @@ struct Wave {
       if (t < D.lmax) acc += m_[t] * vec[(j.rb[s][t >> 2] >> (8 * (t & 3))) & 255];
     return acc;
   }
+  // sum of the c <= cmax consecutive piece sums of this lane's column / row (fixed trip count, reads masked by select)
+  static __device__ __forceinline__ float merge_pieces(const float* part, int t0, int c, int cmax) {
+    float sum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      if (r < cmax) { const float v = part[t0 + r]; sum += r < c ? v : 0.0f; }
+    return sum;
+  }
   __device__ __forceinline__ void ldl_solve(float* x) {
     Jobs jb;
     load_jobs(jb);
@@ -890,10 +898,7 @@ struct Wave {
     float y[NVS];
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
-      const int t0 = jb.own[s] & 255, c = (jb.own[s] >> 8) & 255;
-      float sum = 0.0f;
-      for (int r = 0; r < c; ++r) sum += s_buf[t0 + r];
-      y[s] = (x[s] - sum) * dinv[s];
+      y[s] = (x[s] - merge_pieces(s_buf, jb.own[s] & 255, (jb.own[s] >> 8) & 255, D.cmax)) * dinv[s];
     }
     // every lane has taken its column pieces of x (hand-off above): the vector cells can take y
 #pragma unroll
@@ -904,10 +909,7 @@ struct Wave {
     sync();
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
-      const int t0 = (jb.own[s] >> 16) & 255, c = (int)((unsigned)jb.own[s] >> 24);
-      float sum = 0.0f;
-      for (int r = 0; r < c; ++r) sum += s_buf[t0 + r];
-      x[s] = y[s] - sum;
+      x[s] = y[s] - merge_pieces(s_buf, (jb.own[s] >> 16) & 255, (int)((unsigned)jb.own[s] >> 24), D.rmax);
     }
     sync();     // s_buf is reused by the next solve
   }
@@ -931,9 +933,8 @@ struct Wave {
       float sum = 0.0f;
       if (d < D.nv) {
         sum = s_qM[opaque(dofc1[s]) & 0xFFFF] * s_vec[d];
-        const int t0 = jb.own[s] & 255, c = (jb.own[s] >> 8) & 255, r0 = (jb.own[s] >> 16) & 255, cr = (int)((unsigned)jb.own[s] >> 24);
-        for (int r = 0; r < c; ++r) sum += s_buf[t0 + r];
-        for (int r = 0; r < cr; ++r) sum += s_buf[WJ + r0 + r];
+        sum += merge_pieces(s_buf, jb.own[s] & 255, (jb.own[s] >> 8) & 255, D.cmax);
+        sum += merge_pieces(s_buf + WJ, (jb.own[s] >> 16) & 255, (int)((unsigned)jb.own[s] >> 24), D.rmax);
       }
       y[s] = sum;
     }

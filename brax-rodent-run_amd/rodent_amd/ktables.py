@@ -280,6 +280,8 @@ def build_kernel_tables(m):
                 rowjob[u >> 2, t] |= int(chain[pp]) << (8 * (u & 3))
             t += 1
     k["k_solve_lmax"] = np.int32(lmax)
+    k["k_solve_cmax"] = np.int32(max(int((o >> 8) & 255) for o in own))     # most pieces of one column / row
+    k["k_solve_rmax"] = np.int32(max(int(o >> 24) for o in own))
     k["k_coljob"] = (coljob & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
     k["k_rowjob"] = (rowjob & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
     k["k_jobown"] = (own & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
