@@ -50,14 +50,14 @@ constexpr RRLayout rr_layout(int nq, int nv, int nu, int nbody, int nM, int ncon
   RRLayout k{};
   int o = 0;
   k.o_qpos = o; o += rr_up4(nq);
-  k.o_qvel = o; o += rr_up4(nv);
+  k.o_qvel = o; o += rr_up4(nv + 1);         // cell nv holds 0 (padding of the J*x jobs)
   k.o_act = o; o += rr_up4(nu);
   k.o_ctrl = o; o += rr_up4(nu);
   // pose cells (xpos | xquat) are recycled as the 6*nv scratch of the mass-matrix build and as solver staging
   k.o_xpos = o; o += rr_up4(rr_imax(7 * nbody + 4, 6 * nv));
   k.o_xquat = k.o_xpos + rr_up4(3 * nbody);
   k.o_cinert = o; o += rr_up4(10 * nbody);      // composite inertia accumulates in place
-  k.o_cdof = o; o += rr_up4(6 * nv);
+  k.o_cdof = o; o += rr_up4(6 * nv + 6);     // + a zero motion vector for dof id nv (padding of the J*x jobs)
   k.o_cvel = o; o += rr_up4(6 * nbody);
   k.o_qM = o; o += rr_up4(nM + 16);          // + cells that hold 0: the job descriptors pad with cell nM, padded row steps read on
   k.o_qLD = o; o += rr_up4(rr_imax(rr_imax(nM + 20, 12 * nbody), 2 * nv));   // also cacc | cfrc and the sin/cos scratch
@@ -323,7 +323,6 @@ struct Wave {
   int dofc0[NVS], dofc1[NVS];   // packed per-dof constants: depth | kind<<8 | root<<12 | body<<16 | parent-of-body<<24 ; Madr | last_desc<<16
   // J*x jobs (contact_jobs): the ancestor chains of the contacts in penetration are cut into pieces, one per lane
   int jch[NCS][9];        // dof ids of this lane's piece, 4 per register
-  int jn[NCS];            // entries of the piece (0 = no job)
   int con_rank[NCS];      // rank of this lane's contact among the contacts in penetration
   int con_leaf[NCS];      // last dof of the contact's chain
   int jP, jLp, jnact;     // wave-uniform: lanes per contact (4 / 2 / 1), ids per piece (12 / 20 / 36), contacts in penetration
@@ -1127,16 +1126,22 @@ struct Wave {
 #pragma unroll
     for (int js = 0; js < NCS; ++js) {
       const int J = lane + RR_LANES * js, r = J >> sh, p = J & (jP - 1);
-      jn[js] = 0;
+      const int pad = D.nv * 0x01010101;      // dof id nv: zero motion vector, zero vector cell
 #pragma unroll
-      for (int k = 0; k < 9; ++k) jch[js][k] = 0;
+      for (int k = 0; k < 9; ++k) jch[js][k] = pad;
       if (r < n_act) {
         const int c = s_jlist[r], start = p * jLp;
         const int left = g_int(T.con_i, 8 * c + 4) - start;
-        jn[js] = left < 0 ? 0 : (left > jLp ? jLp : left);
+        const int n = left < 0 ? 0 : (left > jLp ? jLp : left);
 #pragma unroll
-        for (int k = 0; k < 9; ++k)
-          if (4 * k < jLp) jch[js][k] = g_int(T.con_chain_rows, 9 * c + (start >> 2) + k);   // the table has a slack row
+        for (int k = 0; k < 9; ++k) {
+          if (4 * k < jLp) {
+            const int v = g_int(T.con_chain_rows, 9 * c + (start >> 2) + k);   // the table has a slack row
+            const int keep = n - 4 * k;                                          // ids of this int that belong to the piece
+            const unsigned msk = keep >= 4 ? 0xFFFFFFFFu : (keep <= 0 ? 0u : (1u << (8 * keep)) - 1u);
+            jch[js][k] = (v & msk) | (pad & ~msk);
+          }
+        }
       }
     }
   }
@@ -1149,19 +1154,16 @@ struct Wave {
 #pragma unroll
     for (int js = 0; js < NCS; ++js) {
       float w[6] = {0, 0, 0, 0, 0, 0};
-      const int n = jn[js];
 #pragma unroll
       for (int t0 = 0; t0 < 36; t0 += 4) {
-        if (t0 < jLp) {
+        if (t0 < jLp) {     // wave-uniform; no per-lane predicate: ids beyond the piece are nv (zero vector)
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            if (t0 + u < n) {
-              const int dd = (opaque(jch[js][t0 >> 2]) >> (8 * u)) & 255;
-              const float xv = vec[dd];
-              const float* cd = s_cdof + 6 * dd;
+            const int dd = (opaque(jch[js][t0 >> 2]) >> (8 * u)) & 255;
+            const float xv = vec[dd];
+            const float* cd = s_cdof + 6 * dd;
 #pragma unroll
-              for (int i = 0; i < 6; ++i) w[i] += cd[i] * xv;
-            }
+            for (int i = 0; i < 6; ++i) w[i] += cd[i] * xv;
           }
         }
       }
@@ -1590,6 +1592,8 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
     w.qacc[s] = w.Ma[s] = w.grad[s] = w.Mgrad[s] = w.search[s] = w.mv[s] = w.qfrc_con[s] = 0.0f;
   }
   for (int i = lane; i < D.nv; i += RR_LANES) w.s_arm[i] = T.dof_f[16 * i];
+  if (lane < 6) w.s_cdof[6 * D.nv + lane] = 0.0f;
+  if (lane == 0) w.s_qvel[D.nv] = 0.0f;
   if (lane < 16) { w.s_qM[D.nM + lane] = 0.0f; w.s_qLD[D.nM + 4 + lane] = 0.0f; w.s_vec[D.nv + lane] = 0.0f; w.s_x[D.nv + lane] = 0.0f; }   // zero cells the job descriptors pad with / padded steps read
   w.sync();
 
