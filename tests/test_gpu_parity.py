@@ -73,18 +73,19 @@ def test_forward_stages_match_oracle(model_name, oracle_built):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("instance", ["debug_dump", "production"])
-def test_solver_and_substep_match_oracle(oracle_built, instance):
+@pytest.mark.parametrize("model,instance", [("rodent_optimized", "debug_dump"), ("rodent_optimized", "production"),
+                                            ("rodent_new", "production"), ("rodent_pair", "production")])
+def test_solver_and_substep_match_oracle(oracle_built, model, instance):
     """qacc after the CG solve and qpos/qvel after one substep, same inputs (float32 vs float64 oracle), for both kernel
-    instances: the debug-dump instance (generic dimensions) that the stage tests read, and the production instance (no
-    dump, fixed rodent dimensions) that is timed.  The two differ in instruction selection (constant folding / FMA
+    instances: the debug-dump instance (generic dimensions) that the stage tests read, and the production instances (no
+    dump; fixed dimensions for rodent_optimized -- the one that is timed -- and generic ones for the other models).  The two differ in instruction selection (constant folding / FMA
     contraction), so their outputs differ at rounding level; each must meet the same bounds against the oracle."""
     from rodent_amd import assets, hip
     ref = oracle_built
-    N = 48
-    st, M, m = util.settled_states(ref, "rodent_optimized", N, seed=2, iterations=(8, 8))
+    N = 48 if model == "rodent_optimized" else 16
+    st, M, m = util.settled_states(ref, model, N, seed=2, iterations=(8, 8))
     dev = torch.device("cuda:0")
-    batch = hip.Batch(hip.Model(assets.asset_path("rodent_optimized"), 8, 8), N, dev)
+    batch = hip.Batch(hip.Model(assets.asset_path(model), 8, 8), N, dev)
     ctrl = np.random.default_rng(6).uniform(-1, 1, (N, M.nu))
     ds = _to_dev(st, dev)
     dbg = torch.zeros(N, batch.dims.dbg_floats, device=dev)
@@ -112,7 +113,7 @@ def test_solver_and_substep_match_oracle(oracle_built, instance):
         dv = np.abs(d2.get("qvel") - st["qvel"][e]).max()           # scale: the substep's velocity change
         err_qvel.append(np.abs(ds["qvel"][e].cpu().numpy() - d2.get("qvel")).max() / max(dv, 1e-3))
         err_qpos.append(np.abs(ds["qpos"][e].cpu().numpy() - d2.get("qpos")).max())
-    print("%s: qacc rel err: median %.2e max %.2e | qvel err / max|dqvel| max %.2e | qpos abs max %.2e"
+    print(model, "%s: qacc rel err: median %.2e max %.2e | qvel err / max|dqvel| max %.2e | qpos abs max %.2e"
           % (instance, np.median(err_qacc), np.max(err_qacc), np.max(err_qvel), np.max(err_qpos)))
     # a truncated (8-iteration) CG run in float32 vs float64: branchy line search -> allow a few outliers
     assert np.median(err_qacc) < 2e-3
