@@ -317,7 +317,7 @@ struct Wave {
   static constexpr int WC = NCS * RR_LANES;
 
   // ---- model constants held in registers for the whole launch (loaded once, reused by all substeps)
-  BodyC bc0;              // constants of body `lane` (slot 0)
+  BodyC bc0, bc1;         // constants of bodies `lane` (slot 0) and `lane + 64` (slot 1); further slots are loaded at use
   int banc[NBS][2];       // 2^k-th ancestors of the slot's body, k = 0..7, one byte each (0 = none)
   int blast[NBS];         // last body of the subtree (bodies are in DFS order)
   int dofc0[NVS], dofc1[NVS];   // packed per-dof constants: depth | kind<<8 | root<<12 | body<<16 | parent-of-body<<24 ; Madr | last_desc<<16
@@ -374,7 +374,7 @@ struct Wave {
   // T[b] <- T[anc_k(b)] o T[b], anc_{k+1} = anc_k o anc_k (ancestor tables in registers), all bodies busy every
   // round, instead of one serial step per tree level (38-39 of them, a handful of active lanes each).
   // Joint anchors / axes are kept in the parent frame (raw, in the cdof cells) and mapped to the world in com_pos.
-  __device__ __forceinline__ BodyC bodyc(int s) const { return s == 0 ? bc0 : load_bodyc(T, lane + RR_LANES * s, D.nbody); }
+  __device__ __forceinline__ BodyC bodyc(int s) const { return s == 0 ? bc0 : (s == 1 ? bc1 : load_bodyc(T, lane + RR_LANES * s, D.nbody)); }
   // k is a run-time round counter: select the word instead of indexing the register array (a dynamic index would
   // push the whole object into scratch memory)
   __device__ __forceinline__ int anc_at(int s, int k) const { const int wd = k < 4 ? banc[s][0] : banc[s][1]; return (wd >> (8 * (k & 3))) & 255; }
@@ -1613,6 +1613,7 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
     {
       const int ol = opaque(lane);
       w.bc0 = load_bodyc(T, ol, D.nbody);
+      if (NBS > 1) w.bc1 = load_bodyc(T, ol + RR_LANES, D.nbody);
 #pragma unroll
       for (int s = 0; s < NBS; ++s) {
         const int b = ol + RR_LANES * s;
