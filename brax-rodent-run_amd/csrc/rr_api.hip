@@ -267,12 +267,16 @@ static int collect_timing(rr_batch* b) {
   return RR_OK;
 }
 
-static int launch(rr_batch* b, const rr_state* st, const float* ctrl, int n_frames, const rr_env_io* env, const rr_outputs* out, int mode) {
+static int launch(rr_batch* b, const rr_state* st, const float* ctrl, int n_frames, const rr_env_io* env, const rr_outputs* out, int mode,
+                  const rr_state* st_in = nullptr, const int32_t* cur_frame_in = nullptr) {
   if (!b || !st || !st->qpos || !st->qvel || !st->act || !st->qacc_warmstart) return fail(RR_EINVAL, "launch: null state pointer");
+  if (st_in && (!st_in->qpos || !st_in->qvel || !st_in->act || !st_in->qacc_warmstart)) return fail(RR_EINVAL, "launch: null input state pointer");
   if ((mode & 1) && (!ctrl || n_frames <= 0)) return fail(RR_EINVAL, "launch: step needs ctrl and n_frames > 0");
   RRIO io;
   memset(&io, 0, sizeof(io));
   io.qpos = st->qpos; io.qvel = st->qvel; io.act = st->act; io.warm = st->qacc_warmstart; io.ctrl = ctrl;
+  const rr_state* si = st_in ? st_in : st;
+  io.qpos_in = si->qpos; io.qvel_in = si->qvel; io.act_in = si->act; io.warm_in = si->qacc_warmstart;
   if (out) {
     io.o_cinert = out->cinert; io.o_cvel = out->cvel; io.o_qfrc_actuator = out->qfrc_actuator; io.o_xpos = out->xpos;
     io.o_xmat = out->xmat; io.o_com = out->subtree_com; io.dbg = out->debug;
@@ -281,6 +285,7 @@ static int launch(rr_batch* b, const rr_state* st, const float* ctrl, int n_fram
     if (!env->obs || !env->track_pos || !env->cur_frame || env->track_len <= 0) return fail(RR_EINVAL, "launch: env io needs obs, track_pos, cur_frame");
     if ((mode & 1) && (!env->reward || !env->done || !env->metrics)) return fail(RR_EINVAL, "launch: env step needs reward, done, metrics");
     io.track_pos = env->track_pos; io.track_len = env->track_len; io.cur_frame = env->cur_frame; io.obs = env->obs;
+    io.cur_frame_in = cur_frame_in ? cur_frame_in : env->cur_frame;
     io.reward = env->reward; io.done = env->done; io.metrics = env->metrics;
     io.healthy_reward = env->healthy_reward; io.ctrl_cost_weight = env->ctrl_cost_weight; io.z_min = env->healthy_z_min;
     io.z_max = env->healthy_z_max; io.terminate_when_unhealthy = env->terminate_when_unhealthy;
@@ -306,6 +311,16 @@ static int launch(rr_batch* b, const rr_state* st, const float* ctrl, int n_fram
   return RR_OK;
 }
 
+extern "C" int rr_pipeline_step_to(rr_batch* b, const rr_state* in, const rr_state* outst, const float* ctrl, int32_t n_frames, const rr_outputs* out) {
+  if (!in) return fail(RR_EINVAL, "rr_pipeline_step_to: null input state");
+  return launch(b, outst, ctrl, n_frames, nullptr, out, 1, in);
+}
+extern "C" int rr_env_step_to(rr_batch* b, const rr_state* in, const rr_state* outst, const float* action, int32_t n_frames, const rr_env_io* env,
+                              const int32_t* cur_frame_in, const rr_outputs* out) {
+  if (!env) return fail(RR_EINVAL, "rr_env_step_to: env io required");
+  if (!in || !cur_frame_in) return fail(RR_EINVAL, "rr_env_step_to: null input state");
+  return launch(b, outst, action, n_frames, env, out, 1, in, cur_frame_in);
+}
 extern "C" int rr_pipeline_init(rr_batch* b, const rr_state* st, const rr_outputs* out) { return launch(b, st, nullptr, 1, nullptr, out, 0); }
 extern "C" int rr_pipeline_step(rr_batch* b, const rr_state* st, const float* ctrl, int32_t n_frames, const rr_outputs* out) {
   return launch(b, st, ctrl, n_frames, nullptr, out, 1);

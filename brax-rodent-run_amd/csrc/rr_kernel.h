@@ -102,7 +102,9 @@ struct RRTables {
 };
 
 struct RRIO {
-  float *qpos, *qvel, *act, *warm;
+  float *qpos, *qvel, *act, *warm;                         // state written by the launch
+  const float *qpos_in, *qvel_in, *act_in, *warm_in;       // state read (== the above for an in-place step)
+  const int* cur_frame_in;
   const float* ctrl;
   float *o_cinert, *o_cvel, *o_qfrc_actuator, *o_xpos, *o_xmat, *o_com, *dbg;
   // env epilogue
@@ -1571,16 +1573,16 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
   float* dbg = (DBG && io.dbg) ? io.dbg + (size_t)env * D.dbg_floats : nullptr;
 
   // ---- load state
-  for (int i = lane; i < D.nq; i += RR_LANES) w.s_qpos[i] = io.qpos[(size_t)env * D.nq + i];
-  for (int i = lane; i < D.nv; i += RR_LANES) w.s_qvel[i] = io.qvel[(size_t)env * D.nv + i];
+  for (int i = lane; i < D.nq; i += RR_LANES) w.s_qpos[i] = io.qpos_in[(size_t)env * D.nq + i];
+  for (int i = lane; i < D.nv; i += RR_LANES) w.s_qvel[i] = io.qvel_in[(size_t)env * D.nv + i];
   for (int i = lane; i < D.nu; i += RR_LANES) {
-    w.s_act[i] = io.act[(size_t)env * D.nu + i];
+    w.s_act[i] = io.act_in[(size_t)env * D.nu + i];
     w.s_ctrl[i] = io.ctrl ? io.ctrl[(size_t)env * D.nu + i] : 0.0f;
   }
 #pragma unroll
   for (int s = 0; s < NVS; ++s) {
     const int d = lane + RR_LANES * s;
-    if (d < D.nv) w.s_warm[d] = io.warm[(size_t)env * D.nv + d];
+    if (d < D.nv) w.s_warm[d] = io.warm_in[(size_t)env * D.nv + d];
     if (d < D.nv) {
       auto di = T.dof_i + RR_DOFI * d;
       w.dofc0[s] = (di[3] & 255) | ((di[2] & 15) << 8) | ((di[9] & 15) << 12) | ((di[0] & 255) << 16) | ((T.body_i[RR_BODYI * di[0]] & 255) << 24);
@@ -1741,7 +1743,7 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
   // ---- reference env epilogue [REF Rodent_Env_Brax.py:103-158]
   if (io.obs) {
     const bool is_reset = (mode & 2) != 0;
-    const int old_frame = io.cur_frame[env];
+    const int old_frame = io.cur_frame_in[env];
     const int new_frame = is_reset ? old_frame : old_frame + 1;
     float* ob = io.obs + (size_t)env * D.obs_dim;
     int o = 0;

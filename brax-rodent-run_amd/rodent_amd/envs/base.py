@@ -116,8 +116,9 @@ class PipelineEnv:
         return PipelineState(**st, **out)
 
     def pipeline_step(self, pipeline_state: PipelineState, action: torch.Tensor) -> PipelineState:
-        st = dict(qpos=pipeline_state.qpos.clone(), qvel=pipeline_state.qvel.clone(), act=pipeline_state.act.clone(),
-                  qacc_warmstart=pipeline_state.qacc_warmstart.clone())
+        st_in = dict(qpos=pipeline_state.qpos, qvel=pipeline_state.qvel, act=pipeline_state.act,
+                     qacc_warmstart=pipeline_state.qacc_warmstart)
+        st = {k: torch.empty_like(v) for k, v in st_in.items()}      # out of place: the argument stays valid
         out = self._alloc_outputs()
-        self._batch.pipeline_step(st, action.to(self.device, torch.float32).contiguous(), self._n_frames, out)
+        self._batch.pipeline_step_to(st_in, st, action.to(self.device, torch.float32).contiguous(), self._n_frames, out)
         return PipelineState(**st, **out)

@@ -101,14 +101,16 @@ class Rodent(PipelineEnv):
         """Runs one timestep of the environment's dynamics."""
         N, dev, s = self.num_envs, self.device, self.sys
         ps = state.pipeline_state
-        st = dict(qpos=ps.qpos.clone(), qvel=ps.qvel.clone(), act=ps.act.clone(), qacc_warmstart=ps.qacc_warmstart.clone())
+        st_in = dict(qpos=ps.qpos, qvel=ps.qvel, act=ps.act, qacc_warmstart=ps.qacc_warmstart)
+        st = {k: torch.empty_like(v) for k, v in st_in.items()}      # the previous state is left untouched (no copies)
         out = self._alloc_outputs()
-        cur_frame = state.info["cur_frame"].clone()
+        cur_frame = torch.empty_like(state.info["cur_frame"])
         obs = torch.empty(N, s.obs_dim, device=dev)
         reward, done = torch.empty(N, device=dev), torch.empty(N, device=dev)
         metrics = torch.empty(N, 3, device=dev)
         action = action.to(dev, torch.float32).contiguous()
-        self._batch.env_step(st, action, self._n_frames, self._env_io(cur_frame, obs, reward, done, metrics), out)
+        self._batch.env_step_to(st_in, st, action, self._n_frames, self._env_io(cur_frame, obs, reward, done, metrics),
+                                state.info["cur_frame"], out)
         info = dict(state.info)
         info["cur_frame"] = cur_frame
         m = dict(state.metrics)

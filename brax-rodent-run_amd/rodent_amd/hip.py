@@ -38,7 +38,7 @@ class RREnvIO(C.Structure):
 
 
 EXPORTS = ["rr_model_load", "rr_model_dims", "rr_model_set_solver", "rr_model_destroy", "rr_batch_create",
-           "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset",
+           "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset", "rr_pipeline_step_to", "rr_env_step_to",
            "rr_compute_gae", "rr_debug_layout", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
 
 _lib = None
@@ -64,6 +64,9 @@ def lib():
         L.rr_pipeline_step.argtypes = [C.c_void_p, C.POINTER(RRState), C.c_void_p, C.c_int32, C.POINTER(RROutputs)]
         L.rr_env_step.argtypes = [C.c_void_p, C.POINTER(RRState), C.c_void_p, C.c_int32, C.POINTER(RREnvIO),
                                   C.POINTER(RROutputs)]
+        L.rr_pipeline_step_to.argtypes = [C.c_void_p, C.POINTER(RRState), C.POINTER(RRState), C.c_void_p, C.c_int32, C.POINTER(RROutputs)]
+        L.rr_env_step_to.argtypes = [C.c_void_p, C.POINTER(RRState), C.POINTER(RRState), C.c_void_p, C.c_int32, C.POINTER(RREnvIO),
+                                     C.c_void_p, C.POINTER(RROutputs)]
         L.rr_env_reset.argtypes = [C.c_void_p, C.POINTER(RRState), C.POINTER(RREnvIO), C.POINTER(RROutputs)]
         L.rr_debug_layout.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_int32)),
                                       C.POINTER(C.POINTER(C.c_int32))]
@@ -190,6 +193,18 @@ class Batch:
         o = self._outputs(out)
         _check(lib().rr_env_step(self.h, C.byref(self._state(st)), _ptr(action, numel=self.N * self.dims.nu),
                                  int(n_frames), C.byref(self._env(env)), C.byref(o) if o else None))
+
+    def pipeline_step_to(self, st_in, st_out, ctrl, n_frames: int, out=None):
+        """Out-of-place pipeline_step: reads st_in, writes st_out (no copies of the previous state needed)."""
+        o = self._outputs(out)
+        _check(lib().rr_pipeline_step_to(self.h, C.byref(self._state(st_in)), C.byref(self._state(st_out)),
+                                         _ptr(ctrl, numel=self.N * self.dims.nu), int(n_frames), C.byref(o) if o else None))
+
+    def env_step_to(self, st_in, st_out, action, n_frames: int, env, cur_frame_in, out=None):
+        o = self._outputs(out)
+        _check(lib().rr_env_step_to(self.h, C.byref(self._state(st_in)), C.byref(self._state(st_out)),
+                                    _ptr(action, numel=self.N * self.dims.nu), int(n_frames), C.byref(self._env(env)),
+                                    _ptr(cur_frame_in, torch.int32, self.N), C.byref(o) if o else None))
 
     def env_reset(self, st, env, out=None):
         o = self._outputs(out)

@@ -102,6 +102,15 @@ int rr_pipeline_step(rr_batch* b, const rr_state* st, const float* ctrl, int32_t
 int rr_env_step(rr_batch* b, const rr_state* st, const float* action, int32_t n_frames, const rr_env_io* env,
                 const rr_outputs* out);
 
+/* Out-of-place variants: read the state from `in` (and info['cur_frame'] from `cur_frame_in`), write the stepped state to
+ * `out_state` (and env->cur_frame).  brax states are immutable values [REF Rodent_Env_Brax.py:98-136 returns a new State]:
+ * a caller that keeps the previous state (rollout buffers, AutoReset's first state) needs no copies.  `in` and
+ * `out_state` may alias field by field (then it is the in-place call). */
+int rr_pipeline_step_to(rr_batch* b, const rr_state* in, const rr_state* out_state, const float* ctrl, int32_t n_frames,
+                        const rr_outputs* out);
+int rr_env_step_to(rr_batch* b, const rr_state* in, const rr_state* out_state, const float* action, int32_t n_frames,
+                   const rr_env_io* env, const int32_t* cur_frame_in, const rr_outputs* out);
+
 /* obs of Rodent.reset: after rr_pipeline_init, obs = _get_obs(data, 0, cur_frame) [REF :89];
  * implemented as rr_pipeline_init + obs epilogue in one launch. Only env->obs/track_pos/cur_frame are used. */
 int rr_env_reset(rr_batch* b, const rr_state* st, const rr_env_io* env, const rr_outputs* out);
