@@ -48,7 +48,7 @@ static void layout(rr_model* m) {
   k.o_arm = L.o_arm; k.o_warm = L.o_warm; k.o_qact = L.o_qact; k.o_jlist = L.o_jlist; k.lds_floats = L.lds_floats;
   const int o = L.lds_floats;
   // staging of the line search's compacted rows: cinert | cvel | pose regions each hold 4*ncon + nv floats
-  m->stage_ok = 6 * d.ncon <= std::max(7 * d.nbody + 4, 6 * d.nv) && 4 * d.ncon + d.nv <= std::min(std::min(10 * d.nbody, 6 * d.nbody), std::max(7 * d.nbody + 4, 6 * d.nv));
+  m->stage_ok = 2 * (d.nbody + 8) <= std::max(7 * d.nbody + 4, 6 * d.nv) && 6 * d.ncon <= std::max(7 * d.nbody + 4, 6 * d.nv) && 4 * d.ncon + d.nv <= std::min(std::min(10 * d.nbody, 6 * d.nbody), std::max(7 * d.nbody + 4, 6 * d.nv));
   // debug dump
   int g = 0;
   auto dbg = [&](const char* name, int n) { int r = g; m->dbg_names.push_back(name); m->dbg_off.push_back(g); m->dbg_size.push_back(n); g += n; return r; };

@@ -675,6 +675,26 @@ struct Wave {
   // own range straight from LDS (no level steps, no hand-offs), keeps the 16 sums in registers, and the results are
   // written back in place after all reads.
   __device__ __forceinline__ void backward_sweep() {
+    // Bodies are in DFS order, so a subtree is the contiguous range [b, blast]; the root's range is the whole tree (65
+    // terms on one lane while most lanes have a handful).  Two levels: sums of aligned blocks of 8 bodies first (all lanes
+    // busy, into the dead pose cells), then every lane adds <= 7 head bodies, <= nbody/8 whole blocks and <= 7 tail bodies.
+    constexpr int BS = 8;
+    const int nblk = (D.nbody + BS - 1) / BS;
+    for (int p = lane; p < 10 * nblk; p += RR_LANES) {
+      const int blk = p / 10, k = p - 10 * blk;
+      float sum = 0.0f;
+#pragma unroll
+      for (int j = 0; j < BS; ++j) { const int d = blk * BS + j; if (d >= 1 && d < D.nbody) sum += s_cinert[10 * d + k]; }
+      s_buf[16 * blk + k] = sum;
+    }
+    for (int p = lane; p < 6 * nblk; p += RR_LANES) {
+      const int blk = p / 6, k = p - 6 * blk;
+      float sum = 0.0f;
+#pragma unroll
+      for (int j = 0; j < BS; ++j) { const int d = blk * BS + j; if (d >= 1 && d < D.nbody) sum += s_cfrc[6 * d + k]; }
+      s_buf[16 * blk + 10 + k] = sum;
+    }
+    sync();
     float acc[NBS][16];
 #pragma unroll
     for (int s = 0; s < NBS; ++s) {
@@ -682,7 +702,21 @@ struct Wave {
 #pragma unroll
       for (int k = 0; k < 16; ++k) acc[s][k] = 0.0f;
       if (b >= 1 && b < D.nbody) {
-        for (int d = b; d <= blast[s]; ++d) {
+        const int e = blast[s] + 1;                                   // range [b, e)
+        int d = b;
+        const int hb = ((b + BS - 1) & ~(BS - 1)) < e ? ((b + BS - 1) & ~(BS - 1)) : e;
+        for (; d < hb; ++d) {
+#pragma unroll
+          for (int k = 0; k < 10; ++k) acc[s][k] += s_cinert[10 * d + k];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) acc[s][10 + k] += s_cfrc[6 * d + k];
+        }
+        for (; d + BS <= e; d += BS) {
+          const float* S = s_buf + 2 * d;                             // 16 * (d / 8)
+#pragma unroll
+          for (int k = 0; k < 16; ++k) acc[s][k] += S[k];
+        }
+        for (; d < e; ++d) {
 #pragma unroll
           for (int k = 0; k < 10; ++k) acc[s][k] += s_cinert[10 * d + k];
 #pragma unroll
