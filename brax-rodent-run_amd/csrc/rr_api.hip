@@ -368,6 +368,53 @@ extern "C" int rr_compute_gae(const float* truncation, const float* termination,
   return RR_OK;
 }
 
+// ------------------------------------------------------------------------------------------ training wrappers, fused
+// brax.envs.wrappers.training: EpisodeWrapper (step count, truncation, done at episode end) followed by AutoResetWrapper
+// (restore the stored first state where done) -- ~15 elementwise launches per env step when composed from tensor ops;
+// here one launch, one 256-thread block per env.  Arrays are row-major [N][width]; `cur` is overwritten in place.
+#define RR_WRAP_MAX 12
+struct RRWrapArgs { const float* first[RR_WRAP_MAX]; float* cur[RR_WRAP_MAX]; int width[RR_WRAP_MAX]; int narr; };
+__global__ void rr_wrap_kernel(const RRWrapArgs A, const float* __restrict__ prev_done, const float* __restrict__ prev_steps,
+                               float* __restrict__ done, float* __restrict__ steps, float* __restrict__ truncation,
+                               float episode_length, float action_repeat) {
+  const int e = blockIdx.x;
+  // AutoReset (before the step): steps <- 0 where the incoming state was done;  Episode: steps += action_repeat, done at the
+  // episode end, truncation = over & !terminated;  AutoReset (after): first state where done
+  const float s0 = prev_done[e] != 0.0f ? 0.0f : prev_steps[e];
+  const float s1 = s0 + action_repeat;
+  const bool over = s1 >= episode_length;
+  const float d_env = done[e];
+  const float d_out = over ? 1.0f : d_env;
+  __syncthreads();                       // every thread has read done[e] before thread 0 rewrites it
+  if (threadIdx.x == 0) { steps[e] = s1; truncation[e] = over ? 1.0f - d_env : 0.0f; done[e] = d_out; }
+  if (d_out != 0.0f) {
+    for (int a = 0; a < A.narr; ++a) {
+      const int w = A.width[a];
+      const float* src = A.first[a] + (size_t)e * w;
+      float* dst = A.cur[a] + (size_t)e * w;
+      for (int i = threadIdx.x; i < w; i += blockDim.x) dst[i] = src[i];
+    }
+  }
+}
+
+extern "C" int rr_wrap_episode_autoreset(int32_t num_envs, int32_t narr, const float* const* first, float* const* cur, const int32_t* widths,
+                                         const float* prev_done, const float* prev_steps, float* done, float* steps, float* truncation,
+                                         float episode_length, float action_repeat, void* stream) {
+  if (num_envs <= 0 || narr < 0 || narr > RR_WRAP_MAX || !prev_done || !prev_steps || !done || !steps || !truncation)
+    return fail(RR_EINVAL, "rr_wrap_episode_autoreset: bad argument");
+  RRWrapArgs A;
+  memset(&A, 0, sizeof(A));
+  A.narr = narr;
+  for (int i = 0; i < narr; ++i) {
+    if (!first[i] || !cur[i] || widths[i] <= 0) return fail(RR_EINVAL, "rr_wrap_episode_autoreset: null array");
+    A.first[i] = first[i]; A.cur[i] = cur[i]; A.width[i] = widths[i];
+  }
+  hipLaunchKernelGGL(rr_wrap_kernel, dim3(num_envs), dim3(256), 0, (hipStream_t)stream, A, prev_done, prev_steps, done, steps, truncation,
+                     episode_length, action_repeat);
+  HIPCHK(hipGetLastError());
+  return RR_OK;
+}
+
 extern "C" int rr_debug_layout(const rr_batch* b, const char*** names, const int32_t** offsets, const int32_t** sizes) {
   if (!b) return fail(RR_EINVAL, "rr_debug_layout: null batch");
   if (names) *names = const_cast<const char**>(b->m->dbg_cnames.data());

@@ -135,8 +135,47 @@ class EvalWrapper(Wrapper):
         return nstate
 
 
+class FusedEpisodeAutoResetWrapper(Wrapper):
+    """EpisodeWrapper + AutoResetWrapper of a HIP env with action_repeat 1: the same values, but the ~15 elementwise
+    launches of the composed wrappers (step count, truncation, done, ten `where(done, first, current)` selects) are one
+    launch of `rr_wrap_episode_autoreset` on the freshly produced state.  `tests/test_gpu_env.py` holds it to bitwise
+    equality with the composition."""
+
+    def __init__(self, env, episode_length: int):
+        super().__init__(env)
+        self.episode_length = episode_length
+        self.action_repeat = 1
+
+    def reset(self, rng):
+        state = self.env.reset(rng)
+        state.info["steps"] = torch.zeros_like(state.reward)
+        state.info["truncation"] = torch.zeros_like(state.reward)
+        state.info["first_pipeline_state"] = state.pipeline_state
+        state.info["first_obs"] = state.obs
+        return state
+
+    def step(self, state, action):
+        from .. import hip
+        nstate = self.env.step(state, action)              # fresh tensors: safe to finish in place
+        fps, ps = nstate.info["first_pipeline_state"], nstate.pipeline_state
+        names = [f.name for f in dataclasses.fields(ps) if torch.is_tensor(getattr(ps, f.name))]
+        first = [getattr(fps, n) for n in names] + [nstate.info["first_obs"]]
+        cur = [getattr(ps, n) for n in names] + [nstate.obs]
+        steps, trunc = torch.empty_like(nstate.done), torch.empty_like(nstate.done)
+        hip.wrap_episode_autoreset(first, cur, state.done, state.info["steps"], nstate.done, steps, trunc,
+                                   self.episode_length, 1)
+        nstate.info["steps"] = steps
+        nstate.info["truncation"] = trunc
+        return nstate
+
+
 def wrap(env, episode_length: int = 1000, action_repeat: int = 1):
-    """brax.envs.wrappers.training.wrap: Vmap -> Episode -> AutoReset."""
+    """brax.envs.wrappers.training.wrap: Vmap -> Episode -> AutoReset (one fused wrapper for a HIP env with
+    action_repeat 1; RR_FUSED_WRAPPERS=0 selects the composition)."""
+    import os
+    base = env.unwrapped if hasattr(env, "unwrapped") else env
+    if action_repeat == 1 and hasattr(base, "_batch") and os.environ.get("RR_FUSED_WRAPPERS", "1") == "1":
+        return FusedEpisodeAutoResetWrapper(VmapWrapper(env), episode_length)
     env = VmapWrapper(env)
     env = EpisodeWrapper(env, episode_length, action_repeat)
     return AutoResetWrapper(env)

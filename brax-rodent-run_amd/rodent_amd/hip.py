@@ -39,7 +39,7 @@ class RREnvIO(C.Structure):
 
 EXPORTS = ["rr_model_load", "rr_model_dims", "rr_model_set_solver", "rr_model_destroy", "rr_batch_create",
            "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset", "rr_pipeline_step_to", "rr_env_step_to",
-           "rr_compute_gae", "rr_debug_layout", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
+           "rr_compute_gae", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
 
 _lib = None
 
@@ -71,6 +71,8 @@ def lib():
         L.rr_debug_layout.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_int32)),
                                       C.POINTER(C.POINTER(C.c_int32))]
         L.rr_compute_gae.argtypes = [C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rr_wrap_episode_autoreset.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32)] + \
+            [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_void_p]
         L.rr_batch_set_profile.argtypes = [C.c_void_p, C.c_void_p]
         L.rr_batch_set_timing.argtypes = [C.c_void_p, C.c_int32]
         L.rr_batch_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -240,3 +242,21 @@ def compute_gae(truncation, termination, rewards, values, bootstrap_value, lambd
     _check(lib().rr_compute_gae(*[t.data_ptr() for t in args], T, B, float(lambda_), float(discount), vs.data_ptr(),
                                 adv.data_ptr(), C.c_void_p(stream)))
     return vs, adv
+
+
+def wrap_episode_autoreset(first, cur, prev_done, prev_steps, done, steps, truncation, episode_length: float, action_repeat: float):
+    """Fused EpisodeWrapper + AutoResetWrapper bookkeeping (C ABI `rr_wrap_episode_autoreset`): `first` / `cur` are equally
+    long lists of contiguous float32 device tensors with a leading env axis; `cur`, `done`, `steps`, `truncation` are written."""
+    n = len(cur)
+    N = done.numel()
+    for t in list(first) + list(cur) + [prev_done, prev_steps, done, steps, truncation]:
+        _ptr(t)
+    F = (C.c_void_p * n)(*[t.data_ptr() for t in first])
+    Cu = (C.c_void_p * n)(*[t.data_ptr() for t in cur])
+    W = (C.c_int32 * n)(*[t.numel() // N for t in cur])
+    for f, c in zip(first, cur):
+        if f.shape != c.shape:
+            raise ValueError("first / current state shapes differ")
+    stream = torch.cuda.current_stream(done.device).cuda_stream
+    _check(lib().rr_wrap_episode_autoreset(N, n, F, Cu, W, prev_done.data_ptr(), prev_steps.data_ptr(), done.data_ptr(), steps.data_ptr(),
+                                           truncation.data_ptr(), float(episode_length), float(action_repeat), C.c_void_p(stream)))

@@ -122,6 +122,15 @@ int rr_compute_gae(const float* truncation, const float* termination, const floa
                    const float* bootstrap_value, int32_t T, int32_t B, float lambda_, float discount, float* vs,
                    float* advantages, void* stream);
 
+/* brax.envs.wrappers.training.EpisodeWrapper + AutoResetWrapper [UP; SURVEY.md 3.4] after an env step, in one launch:
+ * steps' = (prev_done ? 0 : prev_steps) + action_repeat; over = steps' >= episode_length; done <- over ? 1 : done;
+ * truncation = over ? 1 - done_env : 0; and for every env with done != 0 the rows of the `narr` (<= 12) arrays `cur[i]`
+ * ([N][widths[i]], overwritten in place) are replaced by the rows of `first[i]` (the state stored at reset).  `first`, `cur`,
+ * `widths` are HOST arrays of device pointers / ints; everything else is device memory.  `info` is not restored (as upstream). */
+int rr_wrap_episode_autoreset(int32_t num_envs, int32_t narr, const float* const* first, float* const* cur, const int32_t* widths,
+                              const float* prev_done, const float* prev_steps, float* done, float* steps, float* truncation,
+                              float episode_length, float action_repeat, void* stream);
+
 /* Debug dump layout: names[i] begins at float offsets[i] of each env's debug row; returns the field count. */
 int rr_debug_layout(const rr_batch* b, const char*** names, const int32_t** offsets, const int32_t** sizes);
 

@@ -58,6 +58,36 @@ def test_step_is_deterministic_across_launches_and_batch_positions():
         assert torch.equal(runs[0][k][perm], st[k]), k
 
 
+def test_fused_training_wrapper_equals_the_composition():
+    """FusedEpisodeAutoResetWrapper (one launch) == AutoResetWrapper(EpisodeWrapper(...)) (tensor ops), bit for bit, through
+    episode ends (episode_length 7), terminations and the restored first states."""
+    import dataclasses
+    from rodent_amd.envs import wrappers as W
+    N = 64
+    env = _mk_env(N)
+    a_env = W.AutoResetWrapper(W.EpisodeWrapper(W.VmapWrapper(env), 7, 1))
+    b_env = W.FusedEpisodeAutoResetWrapper(W.VmapWrapper(env), 7)
+    assert isinstance(W.wrap(env, episode_length=7, action_repeat=1), W.FusedEpisodeAutoResetWrapper)
+    sa, sb = a_env.reset(4), b_env.reset(4)
+    g = torch.Generator(device="cuda:0"); g.manual_seed(9)
+    seen_done = 0
+    for t in range(40):
+        act = torch.rand(N, env.action_size, device="cuda:0", generator=g) * 4 - 2      # wild actions: some envs fall over
+        sa, sb = a_env.step(sa, act), b_env.step(sb, act)
+        seen_done += int(sa.done.sum())
+        for f in dataclasses.fields(sa.pipeline_state):
+            x, y = getattr(sa.pipeline_state, f.name), getattr(sb.pipeline_state, f.name)
+            if torch.is_tensor(x):
+                assert torch.equal(x, y), (t, f.name)
+        for name in ("obs", "reward", "done"):
+            assert torch.equal(getattr(sa, name), getattr(sb, name)), (t, name)
+        for k in ("steps", "truncation", "cur_frame"):
+            assert torch.equal(sa.info[k], sb.info[k]), (t, k)
+        for k in sa.metrics:
+            assert torch.equal(sa.metrics[k], sb.metrics[k]), (t, k)
+    assert seen_done >= 5 * N          # every env went through several episode ends
+
+
 def test_env_step_matches_oracle(oracle_built):
     from rodent_amd import assets
     ref = oracle_built
