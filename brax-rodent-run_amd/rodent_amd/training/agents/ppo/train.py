@@ -10,6 +10,8 @@ once per training step (RCCL over xGMI; gloo in the CPU tests).
 from __future__ import annotations
 
 import math
+import logging
+import os
 import time
 from typing import Callable, Optional, Tuple
 
@@ -108,7 +110,12 @@ def train(
     flat = D.FlatGrads(params)
     # optax.adam(lr): b1=.9, b2=.999, eps=1e-8, eps outside the sqrt -- torch.optim.Adam's update; one fused
     # multi-tensor launch per step on the GPU
-    optimizer = torch.optim.Adam(params, lr=learning_rate, betas=(0.9, 0.999), eps=1e-8, fused=(device.type == "cuda"))
+    # One process on a GPU: the minibatch update (gather, normalise, both MLPs forward + backward, GAE kernel, fused Adam) is
+    # captured once in a HIP graph and replayed -- ~70 small launches per update otherwise leave the GPU idle between them
+    # (half of the learner's wall time at the launcher's sizes).  RR_PPO_GRAPH=0 keeps the eager path.
+    use_graph = device.type == "cuda" and process_count == 1 and os.environ.get("RR_PPO_GRAPH", "1") == "1"
+    optimizer = torch.optim.Adam(params, lr=learning_rate, betas=(0.9, 0.999), eps=1e-8, fused=(device.type == "cuda"),
+                                 capturable=use_graph)
     normalizer_params = running_statistics.init_state(env.observation_size, device)
     normalize = running_statistics.normalize if normalize_observations else (lambda x, y: x)
     make_policy = ppo_networks_mod.make_inference_fn(ppo_network)
@@ -134,6 +141,50 @@ def train(
         if device.type == "cuda":
             torch.cuda.synchronize(device)
 
+    gstate = {"graph": None, "calls": 0, "idx": None, "norm": None, "metrics": None, "failed": False}
+
+    def eager_update(data, idx, nparams):
+        obs = normalize(data["obs"][idx].transpose(0, 1), nparams)     # [T+1, B, obs]
+        mbd = {k: data[k][idx].transpose(0, 1) for k in ("raw_action", "log_prob", "reward", "discount", "truncation")}
+        policy_logits = policy_net(obs[:T])
+        values = value_net(obs).squeeze(-1)
+        loss, m = ppo_losses.compute_ppo_loss(
+            policy_logits, values[:T], values[T], mbd, dist, entropy_cost=entropy_cost, discounting=discounting,
+            reward_scaling=reward_scaling, gae_lambda=gae_lambda, clipping_epsilon=clipping_epsilon,
+            normalize_advantage=normalize_advantage, generator=gen)
+        flat.zero_()
+        loss.backward()
+        flat.pmean_()                            # jax.lax.pmean(grads, 'i')
+        optimizer.step()
+        return m
+
+    def minibatch_update(data, idx):
+        if not use_graph or gstate["failed"]:
+            return eager_update(data, idx, normalizer_params)
+        gstate["calls"] += 1
+        if gstate["graph"] is None:
+            if gstate["calls"] <= 3:             # first updates run eagerly: they create the Adam state and the GEMM workspaces
+                return eager_update(data, idx, normalizer_params)
+            try:                                 # 4th update: capture it, then run it by replaying the capture
+                gstate["idx"] = idx.clone()
+                gstate["norm"] = normalizer_params.clone() if normalize_observations else None
+                g = torch.cuda.CUDAGraph()
+                if hasattr(g, "register_generator_state"):
+                    g.register_generator_state(gen)
+                torch.cuda.synchronize(device)
+                with torch.cuda.graph(g):
+                    gstate["metrics"] = eager_update(data, gstate["idx"], gstate["norm"] if normalize_observations else normalizer_params)
+                gstate["graph"] = g
+            except Exception as e:               # keep training on the eager path
+                gstate["failed"] = True
+                logging.warning("PPO update graph capture failed (%s); continuing eagerly", e)
+                return eager_update(data, idx, normalizer_params)
+            gstate["graph"].replay()
+            return gstate["metrics"]
+        gstate["idx"].copy_(idx)
+        gstate["graph"].replay()
+        return gstate["metrics"]
+
     def training_step():
         nonlocal env_state, normalizer_params
         t0 = time.time()
@@ -146,22 +197,14 @@ def train(
         if normalize_observations:                       # update on `observation` (not next_observation), all ranks
             normalizer_params = running_statistics.update(normalizer_params, buf.obs[:, :, :T])
         metrics = {}
+        if normalize_observations and gstate["norm"] is not None:     # the graph reads the normaliser from fixed buffers
+            for f in ("count", "mean", "summed_variance", "std"):
+                getattr(gstate["norm"], f).copy_(getattr(normalizer_params, f))
         for _ in range(num_updates_per_batch):
             perm = torch.randperm(U * N, generator=perm_gen).to(device)
             for mb in range(num_minibatches):
                 idx = perm[mb * local_batch:(mb + 1) * local_batch]
-                obs = normalize(data["obs"][idx].transpose(0, 1), normalizer_params)     # [T+1, B, obs]
-                mbd = {k: data[k][idx].transpose(0, 1) for k in ("raw_action", "log_prob", "reward", "discount", "truncation")}
-                policy_logits = policy_net(obs[:T])
-                values = value_net(obs).squeeze(-1)
-                loss, metrics = ppo_losses.compute_ppo_loss(
-                    policy_logits, values[:T], values[T], mbd, dist, entropy_cost=entropy_cost, discounting=discounting,
-                    reward_scaling=reward_scaling, gae_lambda=gae_lambda, clipping_epsilon=clipping_epsilon,
-                    normalize_advantage=normalize_advantage, generator=gen)
-                flat.zero_()
-                loss.backward()
-                flat.pmean_()                            # jax.lax.pmean(grads, 'i')
-                optimizer.step()
+                metrics = minibatch_update(data, idx)
         sync()
         t2 = time.time()
         if timing_fn is not None:
