@@ -329,7 +329,8 @@ struct Wave {
   int con_leaf[NCS];      // last dof of the contact's chain
   int jP, jLp, jnact;     // wave-uniform: lanes per contact (4 / 2 / 1), ids per piece (12 / 20 / 36), contacts in penetration
   // per-dof registers (slot s -> dof lane + 64 s)
-  float dinv[NVS];
+  float dinv[NVS], dinvB[NVS];   // 1/D of M's factor, and of the eulerdamp matrix M + dt*diag(damping)
+  float Ma_warm[NVS];            // M * qacc_warmstart, taken before the cells of qM are given to the second factor
   float qfrc_smooth[NVS], qacc_smooth[NVS];
   float qacc[NVS], Ma[NVS], grad[NVS], Mgrad[NVS], search[NVS], mv[NVS], qfrc_con[NVS];
   // limit rows (one per limited hinge dof)
@@ -784,14 +785,17 @@ struct Wave {
   static __device__ __forceinline__ float lds_ld(int byte_adr) { return *(rr_lf)(size_t)(unsigned)byte_adr; }
   static __device__ __forceinline__ void lds_st(int byte_adr, float v) { *(rr_lf)(size_t)(unsigned)byte_adr = v; }
   typedef int rr_v4i __attribute__((ext_vector_type(4)));
+  // DUAL: the same schedule runs on a second array `db` bytes behind the first in the same pass.  The step factorises
+  // two matrices of identical sparsity every substep -- M for the solver, M + dt*diag(damping) for eulerdamp -- so the
+  // table stream, the address extraction, the flags and above all the LDS round trip of a row are shared.
   template <bool DIV>
-  __device__ __forceinline__ void run_levels(rr_gi table, int nrows) {
+  __device__ __forceinline__ void run_levels(rr_gi table, int nrows, const int db) {
     typedef const rr_v4i __attribute__((address_space(1)))* rr_gv4;
     rr_gv4 tab = (rr_gv4)table;
     rr_v4i ring[RR_RING];
 #pragma unroll
     for (int u = 0; u < RR_RING; ++u) ring[u] = tab[u * RR_LANES + lane];
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f}, accB[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int r0 = 0; r0 < nrows; r0 += RR_RING) {
 #pragma unroll
       for (int u = 0; u < RR_RING; ++u) {
@@ -799,24 +803,30 @@ struct Wave {
         ring[u] = tab[(r0 + RR_RING + u) * RR_LANES + lane];
         const int a4 = e.x & 0xFFFF, b4 = (int)((unsigned)e.x >> 16);
         const int d4[4] = {e.y & 0xFFFF, (int)((unsigned)e.y >> 16), e.z & 0xFFFF, (int)((unsigned)e.z >> 16)};
-        const float va = lds_ld(a4);
-        const float vp = DIV ? lds_ld(a4 - (e.w & 0xFF) + 4) : 1.0f;
-        float vb[4], vo[4];
+        const int p4 = a4 - (e.w & 0xFF) + 4;
+        const float va = lds_ld(a4), vaB = lds_ld(a4 + db);
+        const float vp = DIV ? lds_ld(p4) : 1.0f, vpB = DIV ? lds_ld(p4 + db) : 1.0f;
+        float vb[4], vo[4], vbB[4], voB[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { vb[j] = lds_ld(b4 + 4 * j); vo[j] = lds_ld(d4[j]); }
-        float t = va;
-        if (DIV) { float r = __builtin_amdgcn_rcpf(vp); r = r * (2.0f - vp * r); t *= r; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { vbB[j] = lds_ld(b4 + 4 * j + db); voB[j] = lds_ld(d4[j] + db); }
+        float t = va, tB = vaB;
+        if (DIV) {
+          float r = __builtin_amdgcn_rcpf(vp); r = r * (2.0f - vp * r); t *= r;
+          float rB = __builtin_amdgcn_rcpf(vpB); rB = rB * (2.0f - vpB * rB); tB *= rB;
+        }
         const int fl = __builtin_amdgcn_readfirstlane(e.w) >> 8;
         if (DIV) {       // several contribution ranks per target: accumulate, apply on the flagged row
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j] += vb[j] * t;
+          for (int j = 0; j < 4; ++j) { acc[j] += vb[j] * t; accB[j] += vbB[j] * tB; }
           if (fl & 1) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { lds_st(d4[j], vo[j] - acc[j]); acc[j] = 0.0f; }
+            for (int j = 0; j < 4; ++j) { lds_st(d4[j], vo[j] - acc[j]); acc[j] = 0.0f; lds_st(d4[j] + db, voB[j] - accB[j]); accB[j] = 0.0f; }
           }
         } else {         // inversion: one contribution per target and level, every row applies
 #pragma unroll
-          for (int j = 0; j < 4; ++j) lds_st(d4[j], vo[j] - vb[j] * t);
+          for (int j = 0; j < 4; ++j) { lds_st(d4[j], vo[j] - vb[j] * t); lds_st(d4[j] + db, voB[j] - vbB[j] * tB); }
         }
         if (fl & 2) sync();
       }
@@ -828,27 +838,28 @@ struct Wave {
   // them).  The rank-1 updates of a level are grouped by TARGET entry (k_factor3): a lane owns one target per group of 64
   // targets and sums its contributions L_kp L_kq / D_k over the level's dofs k below it, one table row per contribution
   // rank.  Rows are scaled by 1/D afterwards.
-  __device__ __forceinline__ void factor(float damp) {
+  // Both matrices at once: A = M in s_qLD (copied from s_qM), B = M + dt*diag(damping) in place in the cells of s_qM
+  // (M itself is not needed afterwards: the one product with M of the substep, M * qacc_warmstart, is taken before).
+  __device__ __forceinline__ void factor() {
     int ment[NME];          // for the row scaling at the end; requested now, local to this call (not held across the solver)
     load_ment(ment);
+    const int db = (int)((const char*)s_qM - (const char*)s_qLD);
     for (int e = lane; e < D.nM; e += RR_LANES) s_qLD[e] = s_qM[e];
-    if (lane < 4) s_qLD[D.nM + lane] = lane == 1 ? 1.0f : 0.0f;     // cells ZERO, ONE, TRASH (+ pad) of the level schedules
-    sync();
-    if (damp != 0.0f) {
+    if (lane < 4) { s_qLD[D.nM + lane] = lane == 1 ? 1.0f : 0.0f; s_qM[D.nM + lane] = lane == 1 ? 1.0f : 0.0f; }   // cells ZERO, ONE, TRASH (+ pad)
 #pragma unroll
-      for (int s = 0; s < NVS; ++s) {
-        const int d = lane + RR_LANES * s;
-        if (d < D.nv) s_qLD[(opaque(dofc1[s]) & 0xFFFF)] += damp * T.dof_f[16 * d + 1];
-      }
-      sync();
+    for (int s = 0; s < NVS; ++s) {
+      const int d = lane + RR_LANES * s;
+      if (d < D.nv) s_qM[(opaque(dofc1[s]) & 0xFFFF)] += D.dt * T.dof_f[16 * d + 1];
     }
-    run_levels<true>(T.factor3, D.nfac);
+    sync();
+    run_levels<true>(T.factor3, D.nfac, db);
     sync();
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
       const int d = lane + RR_LANES * s;
       dinv[s] = d < D.nv ? 1.0f / s_qLD[(opaque(dofc1[s]) & 0xFFFF)] : 0.0f;
-      if (d < D.nv) s_arm[D.nv + d] = dinv[s];   // s_arm[nv..2nv): 1/D per dof for the row scaling below
+      dinvB[s] = d < D.nv ? 1.0f / s_qM[(opaque(dofc1[s]) & 0xFFFF)] : 0.0f;
+      if (d < D.nv) { s_arm[D.nv + d] = dinv[s]; s_x[d] = dinvB[s]; }   // 1/D per dof for the row scaling below
     }
     sync();
 #pragma unroll
@@ -856,7 +867,7 @@ struct Wave {
       const int ij = ment[it];
       if (ij >= 0) {
         const int i = ij & 255, j = ij >> 8;
-        if (i != j) s_qLD[lane + RR_LANES * it] *= s_arm[D.nv + i];
+        if (i != j) { s_qLD[lane + RR_LANES * it] *= s_arm[D.nv + i]; s_qM[lane + RR_LANES * it] *= s_x[i]; }
       }
     }
     sync();
@@ -867,7 +878,7 @@ struct Wave {
   // of them per factorisation; with W they become two independent sparse products (ldl_solve).  Gauss-Jordan by depth
   // levels, shallow -> deep (k_linv): when the dofs k of a level are processed every descendant row i does
   // W_ia -= W_ik W_ka over the strict ancestors a of k; W_ik still holds L_ik (only deeper levels write it), row k is final.
-  __device__ __forceinline__ void invert() { run_levels<false>(T.linv, D.ninv); }
+  __device__ __forceinline__ void invert() { run_levels<false>(T.linv, D.ninv, (int)((const char*)s_qM - (const char*)s_qLD)); }
 
   // x <- (L' D L)^-1 x = U D^-1 U' x  [MuJoCo mj_solveLD] with the explicit inverse factor U = I - W (see invert): no
   // dependent chain, no atomics.  U' b sums column j over its descendants i (a contiguous DFS range, entry (i, j) at
@@ -921,26 +932,29 @@ struct Wave {
       if (r < cmax) { const float v = part[t0 + r]; sum += r < c ? v : 0.0f; }
     return sum;
   }
+  // DAMPED = true: the factor of M + dt*diag(damping) (cells of s_qM, dinvB)
+  template <bool DAMPED = false>
   __device__ __forceinline__ void ldl_solve(float* x) {
+    const float* mat = DAMPED ? s_qM : s_qLD;
     Jobs jb;
     load_jobs(jb);
 #pragma unroll
     for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; if (d < D.nv) s_x[d] = x[s]; }
     sync();
 #pragma unroll
-    for (int s = 0; s < NJS; ++s) s_buf[s * RR_LANES + lane] = col_piece(jb, s, s_qLD, s_x);
+    for (int s = 0; s < NJS; ++s) s_buf[s * RR_LANES + lane] = col_piece(jb, s, mat, s_x);
     sync();
     float y[NVS];
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
-      y[s] = (x[s] - merge_pieces(s_buf, jb.own[s] & 255, (jb.own[s] >> 8) & 255, D.cmax)) * dinv[s];
+      y[s] = (x[s] - merge_pieces(s_buf, jb.own[s] & 255, (jb.own[s] >> 8) & 255, D.cmax)) * (DAMPED ? dinvB[s] : dinv[s]);
     }
     // every lane has taken its column pieces of x (hand-off above): the vector cells can take y
 #pragma unroll
     for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; if (d < D.nv) s_x[d] = y[s]; }
     sync();
 #pragma unroll
-    for (int s = 0; s < NJS; ++s) s_buf[s * RR_LANES + lane] = row_piece(jb, s, s_qLD, s_x);
+    for (int s = 0; s < NJS; ++s) s_buf[s * RR_LANES + lane] = row_piece(jb, s, mat, s_x);
     sync();
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
@@ -1326,8 +1340,8 @@ struct Wave {
 #pragma unroll
       for (int s = 0; s < NVS; ++s) Ma[s] = qfrc_smooth[s];
     } else {
-      for (int rep = 0; rep < RR_REP_MULM; ++rep) mul_m(Ma);
-      mul_m(Ma);
+#pragma unroll
+      for (int s = 0; s < NVS; ++s) Ma[s] = Ma_warm[s];     // M * qacc_warmstart (taken before the factorisations)
     }
     cost = INFINITY; prev_cost = 0.0f;
     update_constraint();
@@ -1530,12 +1544,10 @@ struct Wave {
 
   // ---------------------------------------------------------------- A-8 euler (+eulerdamp) and position integration
   __device__ __forceinline__ void euler() {
-    factor(D.dt);
-    invert();
     float qa[NVS];
 #pragma unroll
     for (int s = 0; s < NVS; ++s) qa[s] = qfrc_smooth[s] + qfrc_con[s];
-    ldl_solve(qa);
+    ldl_solve<true>(qa);
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
       const int d = lane + RR_LANES * s;
@@ -1720,10 +1732,16 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
     for (int rep = 0; rep < RR_REP_MM; ++rep) w.mass_matrix();
     w.mass_matrix();
     w.template stamp<PROF>(4);
-    for (int rep = 0; rep < RR_REP_FACTOR; ++rep) w.factor(0.0f);
-    w.factor(0.0f);
+    if (dg) for (int e = lane; e < D.nM; e += RR_LANES) dg[D.g_qM + e] = w.s_qM[e];
+    {   // the substep's only product with M itself: M * qacc_warmstart, for the solver's warm-start context
+      float wv[NVS];
+#pragma unroll
+      for (int s = 0; s < NVS; ++s) { const int d = lane + RR_LANES * s; wv[s] = d < D.nv ? w.s_warm[d] : 0.0f; }
+      w.put_vec(wv);
+      w.mul_m(w.Ma_warm);
+    }
+    w.factor();
     if (dg) for (int e = lane; e < D.nM; e += RR_LANES) dg[D.g_qLD + e] = w.s_qLD[e];
-    for (int rep = 0; rep < RR_REP_INV; ++rep) w.invert();
     w.invert();
     w.template stamp<PROF>(5);
 #pragma unroll
@@ -1731,7 +1749,6 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
     w.ldl_solve(w.qacc_smooth);
     w.template stamp<PROF>(6);
     if (dg) {
-      for (int e = lane; e < D.nM; e += RR_LANES) dg[D.g_qM + e] = w.s_qM[e];
 #pragma unroll
       for (int s = 0; s < NVS; ++s) {
         const int d = lane + RR_LANES * s;
