@@ -44,7 +44,7 @@ static void layout(rr_model* m) {
   const rr_dims& d = m->dims;
   const RRLayout L = rr_layout(d.nq, d.nv, d.nu, d.nbody, d.nM, d.ncon);
   k.o_qpos = L.o_qpos; k.o_qvel = L.o_qvel; k.o_act = L.o_act; k.o_ctrl = L.o_ctrl; k.o_xpos = L.o_xpos; k.o_xquat = L.o_xquat;
-  k.o_cinert = L.o_cinert; k.o_cdof = L.o_cdof; k.o_cvel = L.o_cvel; k.o_qM = L.o_qM; k.o_qLD = L.o_qLD; k.o_vec = L.o_vec; k.o_x = L.o_x;
+  k.o_cinert = L.o_cinert; k.o_cdof = L.o_cdof; k.o_cvel = L.o_cvel; k.o_qLD = L.o_qLD; k.o_vec = L.o_vec; k.o_x = L.o_x;
   k.o_arm = L.o_arm; k.o_warm = L.o_warm; k.o_qact = L.o_qact; k.o_jlist = L.o_jlist; k.lds_floats = L.lds_floats;
   const int o = L.lds_floats;
   // staging of the line search's compacted rows: cinert | cvel | pose regions each hold 4*ncon + nv floats
@@ -189,11 +189,10 @@ static int upload_levels(rr_batch* b, const char* name, rr_gi* dst) {
   std::vector<uint32_t> t((const uint32_t*)e->data, (const uint32_t*)e->data + e->count);
   for (size_t i = 0; i + 3 < t.size(); i += 4) {        // x = a | b0 << 16, y = d0 | d1 << 16, z = d2 | d3 << 16, w = q | flags << 8
     uint32_t f[6] = {t[i] & 0xFFFFu, t[i] >> 16, t[i + 1] & 0xFFFFu, t[i + 1] >> 16, t[i + 2] & 0xFFFFu, t[i + 2] >> 16};
-    for (uint32_t& v : f) { v = v * 4u + base; if (v > 0xFFFFu) return fail(RR_EUNSUPPORTED, "level schedule does not fit the 16-bit LDS address fields"); }
-    const uint32_t q = (t[i + 3] & 0xFFu) * 4u;
-    if (q > 0xFFu) return fail(RR_EUNSUPPORTED, "level schedule: pivot offset above 8 bits");
+    for (uint32_t& v : f) { v = v * 8u + base; if (v > 0xFFFFu) return fail(RR_EUNSUPPORTED, "level schedule does not fit the 16-bit LDS address fields"); }   // 8 bytes per entry: pairs
+    const uint32_t q = (t[i + 3] & 0xFFu) * 8u, flags = t[i + 3] >> 8;
     t[i] = f[0] | (f[1] << 16); t[i + 1] = f[2] | (f[3] << 16); t[i + 2] = f[4] | (f[5] << 16);
-    t[i + 3] = q | (t[i + 3] & 0xFFFFFF00u);
+    t[i + 3] = q | (flags << 16);
   }
   void* p = nullptr;
   HIPCHK(hipMalloc(&p, t.size() * 4));

@@ -32,7 +32,7 @@ struct RRDims {
   float dt, gx, gy, gz, tolerance, ls_tolerance, meaninertia;
   // LDS offsets (floats)
   int o_qpos, o_qvel, o_act, o_ctrl, o_xpos, o_xquat, o_cinert, o_cdof, o_cvel,
-      o_qM, o_qLD, o_vec, o_x, o_arm, o_warm, o_qact, o_jlist, lds_floats;
+      o_qLD, o_vec, o_x, o_arm, o_warm, o_qact, o_jlist, lds_floats;
   // debug dump offsets (floats)
   int g_xpos, g_xquat, g_xmat, g_com, g_cinert, g_crb, g_cdof, g_cvel, g_cfrc, g_qM, g_qLD, g_dinv, g_bias, g_passive,
       g_actuator, g_smooth, g_qacc_smooth, g_con_dist, g_con_pos, g_con_frame, g_con_D, g_con_aref, g_lim, g_qacc,
@@ -42,7 +42,7 @@ struct RRDims {
 // LDS layout of one environment (float offsets).  One constexpr function serves the host (rr_api.hip layout) and the
 // kernel instance compiled for fixed model dimensions.
 struct RRLayout {
-  int o_qpos, o_qvel, o_act, o_ctrl, o_xpos, o_xquat, o_cinert, o_cdof, o_cvel, o_qM, o_qLD, o_vec, o_x, o_arm, o_warm, o_qact, o_jlist, lds_floats;
+  int o_qpos, o_qvel, o_act, o_ctrl, o_xpos, o_xquat, o_cinert, o_cdof, o_cvel, o_qLD, o_vec, o_x, o_arm, o_warm, o_qact, o_jlist, lds_floats;
 };
 constexpr int rr_imax(int a, int b) { return a > b ? a : b; }
 constexpr int rr_up4(int n) { return (n + 3) & ~3; }
@@ -59,8 +59,10 @@ constexpr RRLayout rr_layout(int nq, int nv, int nu, int nbody, int nM, int ncon
   k.o_cinert = o; o += rr_up4(10 * nbody);      // composite inertia accumulates in place
   k.o_cdof = o; o += rr_up4(6 * nv + 6);     // + a zero motion vector for dof id nv (padding of the J*x jobs)
   k.o_cvel = o; o += rr_up4(6 * nbody);
-  k.o_qM = o; o += rr_up4(nM + 16);          // + cells that hold 0: the job descriptors pad with cell nM, padded row steps read on
-  k.o_qLD = o; o += rr_up4(rr_imax(rr_imax(nM + 20, 12 * nbody), 2 * nv));   // also cacc | cfrc and the sin/cos scratch
+  // sparse-matrix array of PAIRS (M | M + dt*diag(damping), then their factors, then their inverse factors): nM entries,
+  // the cells ZERO, ONE, TRASH (+ pad) of the level schedules, 16 zero cells padded row jobs read on.  Before the mass
+  // matrix is built its first cells hold cacc | cfrc and the sin/cos scratch.
+  k.o_qLD = o; o += rr_up4(rr_imax(rr_imax(2 * (nM + 20), 12 * nbody), 2 * nv));
   k.o_vec = o; o += rr_up4(nv + 16);         // vector cells nv.. hold 0 (padding of the job descriptors; padded column steps read on)
   k.o_x = o; o += rr_up4(nv + 16);
   k.o_arm = o; o += rr_up4(2 * nv);
@@ -79,7 +81,7 @@ struct RRDimsRodent : RRDims {
   static constexpr int nq = 74, nv = 73, nu = 30, nbody = 66, njnt = 68, nM = 1119, ncon = 59, dmax = 35, nroot = 1, obs_dim = 1263, nround = 6, lmax = 12, cmax = 6, rmax = 3;
   static constexpr RRLayout LY = rr_layout(nq, nv, nu, nbody, nM, ncon);
   static constexpr int o_qpos = LY.o_qpos, o_qvel = LY.o_qvel, o_act = LY.o_act, o_ctrl = LY.o_ctrl, o_xpos = LY.o_xpos, o_xquat = LY.o_xquat,
-                       o_cinert = LY.o_cinert, o_cdof = LY.o_cdof, o_cvel = LY.o_cvel, o_qM = LY.o_qM, o_qLD = LY.o_qLD, o_vec = LY.o_vec,
+                       o_cinert = LY.o_cinert, o_cdof = LY.o_cdof, o_cvel = LY.o_cvel, o_qLD = LY.o_qLD, o_vec = LY.o_vec,
                        o_x = LY.o_x, o_arm = LY.o_arm, o_warm = LY.o_warm, o_qact = LY.o_qact, o_jlist = LY.o_jlist,
                        lds_floats = LY.lds_floats;
   __host__ __device__ RRDimsRodent(const RRDims& d) : RRDims(d) {}
@@ -88,7 +90,7 @@ struct RRDimsRodent : RRDims {
     return r.nq == nq && r.nv == nv && r.nu == nu && r.nbody == nbody && r.njnt == njnt && r.nM == nM && r.ncon == ncon && r.dmax == dmax &&
            r.nroot == nroot && r.obs_dim == obs_dim && r.nround == nround && r.lmax == lmax && r.cmax == cmax && r.rmax == rmax && r.o_qpos == o_qpos && r.o_qvel == o_qvel && r.o_act == o_act &&
            r.o_ctrl == o_ctrl && r.o_xpos == o_xpos && r.o_xquat == o_xquat && r.o_cinert == o_cinert && r.o_cdof == o_cdof &&
-           r.o_cvel == o_cvel && r.o_qM == o_qM && r.o_qLD == o_qLD && r.o_vec == o_vec && r.o_x == o_x && r.o_arm == o_arm &&
+           r.o_cvel == o_cvel && r.o_qLD == o_qLD && r.o_vec == o_vec && r.o_x == o_x && r.o_arm == o_arm &&
            r.o_warm == o_warm && r.o_qact == o_qact && r.o_jlist == o_jlist && r.lds_floats == lds_floats;
   }
 };
@@ -312,7 +314,7 @@ struct Wave {
   // consumed / written out), s_cacc|s_cfrc and the sin/cos scratch live in the region that later holds qLD,
   // s_buf reuses xpos|xquat after the contact geometry has been taken.
   float *s_qpos, *s_qvel, *s_act, *s_ctrl, *s_xpos, *s_xquat, *s_cinert, *s_crb, *s_cdof, *s_cvel, *s_cacc,
-      *s_cfrc, *s_buf, *s_sc, *s_qM, *s_qLD, *s_vec, *s_x, *s_arm, *s_warm, *s_qact;
+      *s_cfrc, *s_buf, *s_sc, *s_qLD, *s_vec, *s_x, *s_arm, *s_warm, *s_qact;
   int* s_jlist;           // contact ids by rank (J*x jobs)
 
   static constexpr int W = NVS * RR_LANES;
@@ -353,7 +355,7 @@ struct Wave {
       : D(d), T(t), lane(threadIdx.x), lds(l) {
     s_qpos = l + d.o_qpos; s_qvel = l + d.o_qvel; s_act = l + d.o_act; s_ctrl = l + d.o_ctrl;
     s_xpos = l + d.o_xpos; s_xquat = l + d.o_xquat; s_cinert = l + d.o_cinert; s_crb = s_cinert;
-    s_cdof = l + d.o_cdof; s_cvel = l + d.o_cvel; s_qM = l + d.o_qM; s_qLD = l + d.o_qLD;
+    s_cdof = l + d.o_cdof; s_cvel = l + d.o_cvel; s_qLD = l + d.o_qLD;
     s_cacc = s_qLD; s_cfrc = s_qLD + 6 * d.nbody; s_sc = s_qLD; s_buf = s_xpos;
     s_vec = l + d.o_vec; s_x = l + d.o_x; s_arm = l + d.o_arm; s_warm = l + d.o_warm; s_qact = l + d.o_qact;
     s_jlist = (int*)(l + d.o_jlist);
@@ -762,7 +764,7 @@ struct Wave {
         const int i = ij & 255, j = ij >> 8;
         float v = dot6(s_cdof + 6 * j, s_buf + 6 * i);
         if (i == j) v = s_arm[i] + v;
-        s_qM[lane + RR_LANES * it] = v;
+        s_qLD[2 * (lane + RR_LANES * it)] = v; s_qLD[2 * (lane + RR_LANES * it) + 1] = v;     // pair: M | (damped copy, see factor)
       }
     }
     sync();
@@ -785,48 +787,51 @@ struct Wave {
   static __device__ __forceinline__ float lds_ld(int byte_adr) { return *(rr_lf)(size_t)(unsigned)byte_adr; }
   static __device__ __forceinline__ void lds_st(int byte_adr, float v) { *(rr_lf)(size_t)(unsigned)byte_adr = v; }
   typedef int rr_v4i __attribute__((ext_vector_type(4)));
-  // DUAL: the same schedule runs on a second array `db` bytes behind the first in the same pass.  The step factorises
-  // two matrices of identical sparsity every substep -- M for the solver, M + dt*diag(damping) for eulerdamp -- so the
-  // table stream, the address extraction, the flags and above all the LDS round trip of a row are shared.
+  // PAIRS: the step factorises two matrices of identical sparsity every substep -- M for the solver and
+  // M + dt*diag(damping) for eulerdamp.  They are stored interleaved (float2 per entry), so one 8-byte LDS operation
+  // serves both: the table stream, the address extraction, the flags and the LDS round trip of a row are shared.
+  typedef float rr_f2 __attribute__((ext_vector_type(2)));
+  typedef rr_f2 __attribute__((address_space(3)))* rr_lf2;
+  static __device__ __forceinline__ rr_f2 lds_ld2(int byte_adr) { return *(rr_lf2)(size_t)(unsigned)byte_adr; }
+  static __device__ __forceinline__ void lds_st2(int byte_adr, rr_f2 v) { *(rr_lf2)(size_t)(unsigned)byte_adr = v; }
   template <bool DIV>
-  __device__ __forceinline__ void run_levels(rr_gi table, int nrows, const int db) {
+  __device__ __forceinline__ void run_levels(rr_gi table, int nrows) {
     typedef const rr_v4i __attribute__((address_space(1)))* rr_gv4;
     rr_gv4 tab = (rr_gv4)table;
     rr_v4i ring[RR_RING];
 #pragma unroll
     for (int u = 0; u < RR_RING; ++u) ring[u] = tab[u * RR_LANES + lane];
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f}, accB[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    rr_f2 acc[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
     for (int r0 = 0; r0 < nrows; r0 += RR_RING) {
 #pragma unroll
       for (int u = 0; u < RR_RING; ++u) {
         const rr_v4i e = ring[u];
         ring[u] = tab[(r0 + RR_RING + u) * RR_LANES + lane];
-        const int a4 = e.x & 0xFFFF, b4 = (int)((unsigned)e.x >> 16);
-        const int d4[4] = {e.y & 0xFFFF, (int)((unsigned)e.y >> 16), e.z & 0xFFFF, (int)((unsigned)e.z >> 16)};
-        const int p4 = a4 - (e.w & 0xFF) + 4;
-        const float va = lds_ld(a4), vaB = lds_ld(a4 + db);
-        const float vp = DIV ? lds_ld(p4) : 1.0f, vpB = DIV ? lds_ld(p4 + db) : 1.0f;
-        float vb[4], vo[4], vbB[4], voB[4];
+        const int a8 = e.x & 0xFFFF, b8 = (int)((unsigned)e.x >> 16);
+        const int d8[4] = {e.y & 0xFFFF, (int)((unsigned)e.y >> 16), e.z & 0xFFFF, (int)((unsigned)e.z >> 16)};
+        const rr_f2 va = lds_ld2(a8);
+        rr_f2 vp = {1.0f, 1.0f};
+        if (DIV) vp = lds_ld2(a8 - (e.w & 0xFFFF) + 8);
+        rr_f2 vb[4], vo[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { vb[j] = lds_ld(b4 + 4 * j); vo[j] = lds_ld(d4[j]); }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { vbB[j] = lds_ld(b4 + 4 * j + db); voB[j] = lds_ld(d4[j] + db); }
-        float t = va, tB = vaB;
+        for (int j = 0; j < 4; ++j) { vb[j] = lds_ld2(b8 + 8 * j); vo[j] = lds_ld2(d8[j]); }
+        rr_f2 t = va;
         if (DIV) {
-          float r = __builtin_amdgcn_rcpf(vp); r = r * (2.0f - vp * r); t *= r;
-          float rB = __builtin_amdgcn_rcpf(vpB); rB = rB * (2.0f - vpB * rB); tB *= rB;
+          rr_f2 r = {__builtin_amdgcn_rcpf(vp.x), __builtin_amdgcn_rcpf(vp.y)};
+          r = r * (2.0f - vp * r);
+          t *= r;
         }
-        const int fl = __builtin_amdgcn_readfirstlane(e.w) >> 8;
+        const int fl = __builtin_amdgcn_readfirstlane(e.w) >> 16;
         if (DIV) {       // several contribution ranks per target: accumulate, apply on the flagged row
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { acc[j] += vb[j] * t; accB[j] += vbB[j] * tB; }
+          for (int j = 0; j < 4; ++j) acc[j] += vb[j] * t;
           if (fl & 1) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { lds_st(d4[j], vo[j] - acc[j]); acc[j] = 0.0f; lds_st(d4[j] + db, voB[j] - accB[j]); accB[j] = 0.0f; }
+            for (int j = 0; j < 4; ++j) { lds_st2(d8[j], vo[j] - acc[j]); acc[j] = rr_f2{0.0f, 0.0f}; }
           }
         } else {         // inversion: one contribution per target and level, every row applies
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { lds_st(d4[j], vo[j] - vb[j] * t); lds_st(d4[j] + db, voB[j] - vbB[j] * tB); }
+          for (int j = 0; j < 4; ++j) lds_st2(d8[j], vo[j] - vb[j] * t);
         }
         if (fl & 2) sync();
       }
@@ -838,27 +843,26 @@ struct Wave {
   // them).  The rank-1 updates of a level are grouped by TARGET entry (k_factor3): a lane owns one target per group of 64
   // targets and sums its contributions L_kp L_kq / D_k over the level's dofs k below it, one table row per contribution
   // rank.  Rows are scaled by 1/D afterwards.
-  // Both matrices at once: A = M in s_qLD (copied from s_qM), B = M + dt*diag(damping) in place in the cells of s_qM
-  // (M itself is not needed afterwards: the one product with M of the substep, M * qacc_warmstart, is taken before).
+  // Both matrices at once: entry e of the array is the pair (M_e, M_e + dt*damping on the diagonal); mass_matrix has
+  // written both halves, the damping is added here.  (M itself is not needed afterwards: the one product with M of the
+  // substep, M * qacc_warmstart, is taken before.)
   __device__ __forceinline__ void factor() {
     int ment[NME];          // for the row scaling at the end; requested now, local to this call (not held across the solver)
     load_ment(ment);
-    const int db = (int)((const char*)s_qM - (const char*)s_qLD);
-    for (int e = lane; e < D.nM; e += RR_LANES) s_qLD[e] = s_qM[e];
-    if (lane < 4) { s_qLD[D.nM + lane] = lane == 1 ? 1.0f : 0.0f; s_qM[D.nM + lane] = lane == 1 ? 1.0f : 0.0f; }   // cells ZERO, ONE, TRASH (+ pad)
+    if (lane < 8) s_qLD[2 * D.nM + lane] = (lane >> 1) == 1 ? 1.0f : 0.0f;     // cells ZERO, ONE, TRASH (+ pad) of the level schedules
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
       const int d = lane + RR_LANES * s;
-      if (d < D.nv) s_qM[(opaque(dofc1[s]) & 0xFFFF)] += D.dt * T.dof_f[16 * d + 1];
+      if (d < D.nv) s_qLD[2 * (opaque(dofc1[s]) & 0xFFFF) + 1] += D.dt * T.dof_f[16 * d + 1];
     }
     sync();
-    run_levels<true>(T.factor3, D.nfac, db);
+    run_levels<true>(T.factor3, D.nfac);
     sync();
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
       const int d = lane + RR_LANES * s;
-      dinv[s] = d < D.nv ? 1.0f / s_qLD[(opaque(dofc1[s]) & 0xFFFF)] : 0.0f;
-      dinvB[s] = d < D.nv ? 1.0f / s_qM[(opaque(dofc1[s]) & 0xFFFF)] : 0.0f;
+      dinv[s] = d < D.nv ? 1.0f / s_qLD[2 * (opaque(dofc1[s]) & 0xFFFF)] : 0.0f;
+      dinvB[s] = d < D.nv ? 1.0f / s_qLD[2 * (opaque(dofc1[s]) & 0xFFFF) + 1] : 0.0f;
       if (d < D.nv) { s_arm[D.nv + d] = dinv[s]; s_x[d] = dinvB[s]; }   // 1/D per dof for the row scaling below
     }
     sync();
@@ -867,7 +871,7 @@ struct Wave {
       const int ij = ment[it];
       if (ij >= 0) {
         const int i = ij & 255, j = ij >> 8;
-        if (i != j) { s_qLD[lane + RR_LANES * it] *= s_arm[D.nv + i]; s_qM[lane + RR_LANES * it] *= s_x[i]; }
+        if (i != j) { s_qLD[2 * (lane + RR_LANES * it)] *= s_arm[D.nv + i]; s_qLD[2 * (lane + RR_LANES * it) + 1] *= s_x[i]; }
       }
     }
     sync();
@@ -878,7 +882,7 @@ struct Wave {
   // of them per factorisation; with W they become two independent sparse products (ldl_solve).  Gauss-Jordan by depth
   // levels, shallow -> deep (k_linv): when the dofs k of a level are processed every descendant row i does
   // W_ia -= W_ik W_ka over the strict ancestors a of k; W_ik still holds L_ik (only deeper levels write it), row k is final.
-  __device__ __forceinline__ void invert() { run_levels<false>(T.linv, D.ninv, (int)((const char*)s_qM - (const char*)s_qLD)); }
+  __device__ __forceinline__ void invert() { run_levels<false>(T.linv, D.ninv); }
 
   // x <- (L' D L)^-1 x = U D^-1 U' x  [MuJoCo mj_solveLD] with the explicit inverse factor U = I - W (see invert): no
   // dependent chain, no atomics.  U' b sums column j over its descendants i (a contiguous DFS range, entry (i, j) at
@@ -907,7 +911,7 @@ struct Wave {
 #pragma unroll
     for (int s = 0; s < NVS; ++s) j.own[s] = ol + RR_LANES * s < D.nv ? g_int(T.jobown, ol + RR_LANES * s) : 0;
   }
-  // column piece: sum_t mat[cw_t] * vec[i0 + t];  row piece: sum_t mat[ra + t] * vec[rb_t]   (mat = s_qLD or s_qM)
+  // column piece: sum_t mat[cw_t] * vec[i0 + t];  row piece: sum_t mat[ra + t] * vec[rb_t]   (mat = one half of the pair array)
   __device__ __forceinline__ float col_piece(const Jobs& j, int s, const float* mat, const float* vec) const {
     const float* v = vec + j.ci0[s];
     float acc = 0.0f;
@@ -921,7 +925,7 @@ struct Wave {
     float acc = 0.0f;
 #pragma unroll
     for (int t = 0; t < 16; ++t)
-      if (t < D.lmax) acc += m_[t] * vec[(j.rb[s][t >> 2] >> (8 * (t & 3))) & 255];
+      if (t < D.lmax) acc += m_[2 * t] * vec[(j.rb[s][t >> 2] >> (8 * (t & 3))) & 255];
     return acc;
   }
   // sum of the c <= cmax consecutive piece sums of this lane's column / row (fixed trip count, reads masked by select)
@@ -932,10 +936,10 @@ struct Wave {
       if (r < cmax) { const float v = part[t0 + r]; sum += r < c ? v : 0.0f; }
     return sum;
   }
-  // DAMPED = true: the factor of M + dt*diag(damping) (cells of s_qM, dinvB)
+  // DAMPED = true: the factor of M + dt*diag(damping) (second half of the pairs, dinvB)
   template <bool DAMPED = false>
   __device__ __forceinline__ void ldl_solve(float* x) {
-    const float* mat = DAMPED ? s_qM : s_qLD;
+    const float* mat = s_qLD + (DAMPED ? 1 : 0);       // half of the pairs
     Jobs jb;
     load_jobs(jb);
 #pragma unroll
@@ -965,15 +969,15 @@ struct Wave {
 
   // y = M * s_vec (s_vec must be visible).  Row i of the symmetric product is its ancestor part (entries of row i) plus
   // its descendant part (entries (k, i) of the rows below): the two sparse products of ldl_solve on the same vector, with
-  // the same balanced jobs (k_coljob / k_rowjob), on s_qM.  No atomics.
+  // the same balanced jobs (k_coljob / k_rowjob), on the first half of the pairs while it still holds M.  No atomics.
   __device__ __forceinline__ void mul_m(float* y) {
     constexpr int WJ = NJS * RR_LANES;
     Jobs jb;
     load_jobs(jb);
 #pragma unroll
     for (int s = 0; s < NJS; ++s) {
-      s_buf[s * RR_LANES + lane] = col_piece(jb, s, s_qM, s_vec);
-      s_buf[WJ + s * RR_LANES + lane] = row_piece(jb, s, s_qM, s_vec);
+      s_buf[s * RR_LANES + lane] = col_piece(jb, s, s_qLD, s_vec);
+      s_buf[WJ + s * RR_LANES + lane] = row_piece(jb, s, s_qLD, s_vec);
     }
     sync();
 #pragma unroll
@@ -981,7 +985,7 @@ struct Wave {
       const int d = lane + RR_LANES * s;
       float sum = 0.0f;
       if (d < D.nv) {
-        sum = s_qM[opaque(dofc1[s]) & 0xFFFF] * s_vec[d];
+        sum = s_qLD[2 * (opaque(dofc1[s]) & 0xFFFF)] * s_vec[d];
         sum += merge_pieces(s_buf, jb.own[s] & 255, (jb.own[s] >> 8) & 255, D.cmax);
         sum += merge_pieces(s_buf + WJ, (jb.own[s] >> 16) & 255, (int)((unsigned)jb.own[s] >> 24), D.rmax);
       }
@@ -1642,7 +1646,8 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
   for (int i = lane; i < D.nv; i += RR_LANES) w.s_arm[i] = T.dof_f[16 * i];
   if (lane < 6) w.s_cdof[6 * D.nv + lane] = 0.0f;
   if (lane == 0) w.s_qvel[D.nv] = 0.0f;
-  if (lane < 16) { w.s_qM[D.nM + lane] = 0.0f; w.s_qLD[D.nM + 4 + lane] = 0.0f; w.s_vec[D.nv + lane] = 0.0f; w.s_x[D.nv + lane] = 0.0f; }   // zero cells the job descriptors pad with / padded steps read
+  if (lane < 40) w.s_qLD[2 * D.nM + lane] = 0.0f;        // cells ZERO .. pad, and the 16 zero cells behind them (pairs)
+  if (lane < 16) { w.s_vec[D.nv + lane] = 0.0f; w.s_x[D.nv + lane] = 0.0f; }   // zero cells the job descriptors pad with / padded steps read
   w.sync();
 
   if (PROF) { for (int i = 0; i < RR_NPH; ++i) w.pt[i] = 0; w.pt_last = __builtin_readcyclecounter(); }
@@ -1732,7 +1737,7 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
     for (int rep = 0; rep < RR_REP_MM; ++rep) w.mass_matrix();
     w.mass_matrix();
     w.template stamp<PROF>(4);
-    if (dg) for (int e = lane; e < D.nM; e += RR_LANES) dg[D.g_qM + e] = w.s_qM[e];
+    if (dg) for (int e = lane; e < D.nM; e += RR_LANES) dg[D.g_qM + e] = w.s_qLD[2 * e];
     {   // the substep's only product with M itself: M * qacc_warmstart, for the solver's warm-start context
       float wv[NVS];
 #pragma unroll
@@ -1741,7 +1746,7 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
       w.mul_m(w.Ma_warm);
     }
     w.factor();
-    if (dg) for (int e = lane; e < D.nM; e += RR_LANES) dg[D.g_qLD + e] = w.s_qLD[e];
+    if (dg) for (int e = lane; e < D.nM; e += RR_LANES) dg[D.g_qLD + e] = w.s_qLD[2 * e];
     w.invert();
     w.template stamp<PROF>(5);
 #pragma unroll

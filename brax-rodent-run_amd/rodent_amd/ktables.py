@@ -138,7 +138,7 @@ def build_kernel_tables(m):
     dmax = int(ddepth.max())
     Wd = NVS * LANES
     by_level = [[i for i in range(nv) if ddepth[i] == l] for l in range(dmax + 1)]
-    if nM >= 4090 or nv >= 255:
+    if 8 * (nM + 20) >= 65536 or nv >= 255:
         raise ValueError("nM above the 12-bit address field of the solve job tables")
 
     # ---- atomic-free factorisation and inversion schedules.  Both are lists of LEVELS; a level is a list of table rows
@@ -241,15 +241,16 @@ def build_kernel_tables(m):
         lmax += 1
     if lmax > 16:
         raise ValueError("solve jobs longer than 16 entries")
-    # Predicate-free job descriptors (the kernel runs every job for lmax steps): a column job lists the byte offsets
-    # 4 * (base[i] - depth[j]) of its matrix entries, 2 per int, padded with the ZERO cell 4 * nM, and walks the vector from
+    # Predicate-free job descriptors (the kernel runs every job for lmax steps).  The matrix array holds PAIRS (entry of
+    # M's factor, entry of the eulerdamp matrix' factor), 8 bytes per entry: a column job lists the byte offsets
+    # 8 * (base[i] - depth[j]) of its matrix entries, 2 per int, padded with the ZERO cell 8 * nM, and walks the vector from
     # i0; a row job lists its ancestor dof ids, 4 per int, padded with nv (a vector cell that always holds 0), and walks
-    # the matrix row from byte offset 4 * (Madr[i] + p0).
+    # the matrix row from byte offset 8 * (Madr[i] + p0).
     coljob = np.zeros((9, nslot), np.int64)     # [0..7]: byte offsets (16 bits each), [8]: i0
     rowjob = np.zeros((5, nslot), np.int64)     # [0..3]: ancestor ids (8 bits each), [4]: byte offset of the first entry
     for t in range(nslot):
         for u in range(16):
-            coljob[u >> 1, t] |= (4 * nM) << (16 * (u & 1))
+            coljob[u >> 1, t] |= (8 * nM) << (16 * (u & 1))
             rowjob[u >> 2, t] |= nv << (8 * (u & 3))
     own = np.zeros(nv, np.int64)                # first column job | count << 8 | first row job << 16 | count << 24
     t = 0
@@ -263,7 +264,7 @@ def build_kernel_tables(m):
             coljob[8, t] = i0
             for u, i in enumerate(range(i0, i1)):
                 coljob[u >> 1, t] &= ~(0xFFFF << (16 * (u & 1)))
-                coljob[u >> 1, t] |= (4 * int(Madr[i] + ddepth[i] - ddepth[j])) << (16 * (u & 1))
+                coljob[u >> 1, t] |= (8 * int(Madr[i] + ddepth[i] - ddepth[j])) << (16 * (u & 1))
             t += 1
     t = 0
     for i in range(nv):
@@ -274,7 +275,7 @@ def build_kernel_tables(m):
         for r in range(c):
             p0 = 1 + r * n // c
             p1 = 1 + (r + 1) * n // c
-            rowjob[4, t] = 4 * int(Madr[i] + p0)
+            rowjob[4, t] = 8 * int(Madr[i] + p0)
             for u, pp in enumerate(range(p0, p1)):
                 rowjob[u >> 2, t] &= ~(0xFF << (8 * (u & 3)))
                 rowjob[u >> 2, t] |= int(chain[pp]) << (8 * (u & 3))

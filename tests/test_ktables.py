@@ -46,16 +46,16 @@ def run_jobs(m, mat, vec, sign):
     pc, pr = np.zeros(nslot), np.zeros(nslot)
     for t in range(nslot):
         i0, adr0 = int(cj[8, t]), int(rj[4, t])
-        assert adr0 % 4 == 0
+        assert adr0 % 8 == 0
         for u in range(lmax):
             off = int(cj[u >> 1, t] >> (16 * (u & 1))) & 0xFFFF
-            assert off % 4 == 0 and off // 4 <= nM
-            pc[t] += mat[off // 4] * xpad[i0 + u]
+            assert off % 8 == 0 and off // 8 <= nM
+            pc[t] += mat[off // 8] * xpad[i0 + u]
             a = int(rj[u >> 2, t] >> (8 * (u & 3))) & 255
             assert a <= nv
-            pr[t] += matpad[adr0 // 4 + u] * x[a]
+            pr[t] += matpad[adr0 // 8 + u] * x[a]
         for u in range(lmax, 16):                            # beyond lmax the descriptors are padding
-            assert (int(cj[u >> 1, t] >> (16 * (u & 1))) & 0xFFFF) == 4 * nM and (int(rj[u >> 2, t] >> (8 * (u & 3))) & 255) == nv
+            assert (int(cj[u >> 1, t] >> (16 * (u & 1))) & 0xFFFF) == 8 * nM and (int(rj[u >> 2, t] >> (8 * (u & 3))) & 255) == nv
     col = np.array([pc[int(o & 255):int(o & 255) + int((o >> 8) & 255)].sum() for o in own])
     row = np.array([pr[int((o >> 16) & 255):int((o >> 16) & 255) + int(o >> 24)].sum() for o in own])
     return sign * col, sign * row
