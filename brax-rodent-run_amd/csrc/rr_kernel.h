@@ -304,6 +304,7 @@ __device__ __forceinline__ BodyC load_bodyc(const RRTables& T, int b, int nbody)
 #ifndef RR_REP_KIN
 #define RR_REP_KIN 0
 #endif
+typedef float rr_f2 __attribute__((ext_vector_type(2)));
 template <int NBS, int NVS, int NCS, class DT>
 struct Wave {
   const DT& D;
@@ -764,7 +765,7 @@ struct Wave {
         const int i = ij & 255, j = ij >> 8;
         float v = dot6(s_cdof + 6 * j, s_buf + 6 * i);
         if (i == j) v = s_arm[i] + v;
-        s_qLD[2 * (lane + RR_LANES * it)] = v; s_qLD[2 * (lane + RR_LANES * it) + 1] = v;     // pair: M | (damped copy, see factor)
+        *(rr_f2*)(s_qLD + 2 * (lane + RR_LANES * it)) = rr_f2{v, v};     // pair: M | (damped copy, see factor); one 8-byte store
       }
     }
     sync();
@@ -790,7 +791,6 @@ struct Wave {
   // PAIRS: the step factorises two matrices of identical sparsity every substep -- M for the solver and
   // M + dt*diag(damping) for eulerdamp.  They are stored interleaved (float2 per entry), so one 8-byte LDS operation
   // serves both: the table stream, the address extraction, the flags and the LDS round trip of a row are shared.
-  typedef float rr_f2 __attribute__((ext_vector_type(2)));
   typedef rr_f2 __attribute__((address_space(3)))* rr_lf2;
   static __device__ __forceinline__ rr_f2 lds_ld2(int byte_adr) { return *(rr_lf2)(size_t)(unsigned)byte_adr; }
   static __device__ __forceinline__ void lds_st2(int byte_adr, rr_f2 v) { *(rr_lf2)(size_t)(unsigned)byte_adr = v; }
@@ -861,9 +861,10 @@ struct Wave {
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
       const int d = lane + RR_LANES * s;
-      dinv[s] = d < D.nv ? 1.0f / s_qLD[2 * (opaque(dofc1[s]) & 0xFFFF)] : 0.0f;
-      dinvB[s] = d < D.nv ? 1.0f / s_qLD[2 * (opaque(dofc1[s]) & 0xFFFF) + 1] : 0.0f;
-      if (d < D.nv) { s_arm[D.nv + d] = dinv[s]; s_x[d] = dinvB[s]; }   // 1/D per dof for the row scaling below
+      const rr_f2 dd = d < D.nv ? *(const rr_f2*)(s_qLD + 2 * (opaque(dofc1[s]) & 0xFFFF)) : rr_f2{1.0f, 1.0f};
+      dinv[s] = d < D.nv ? 1.0f / dd.x : 0.0f;
+      dinvB[s] = d < D.nv ? 1.0f / dd.y : 0.0f;
+      if (d < D.nv) *(rr_f2*)(s_buf + 2 * d) = rr_f2{dinv[s], dinvB[s]};   // 1/D pairs per dof for the row scaling below (dead pose cells)
     }
     sync();
 #pragma unroll
@@ -871,7 +872,7 @@ struct Wave {
       const int ij = ment[it];
       if (ij >= 0) {
         const int i = ij & 255, j = ij >> 8;
-        if (i != j) { s_qLD[2 * (lane + RR_LANES * it)] *= s_arm[D.nv + i]; s_qLD[2 * (lane + RR_LANES * it) + 1] *= s_x[i]; }
+        if (i != j) *(rr_f2*)(s_qLD + 2 * (lane + RR_LANES * it)) *= *(const rr_f2*)(s_buf + 2 * i);
       }
     }
     sync();
