@@ -396,7 +396,9 @@ struct Wave {
         v3 pos = mk3(c.pos[0], c.pos[1], c.pos[2]);
 #pragma unroll
         for (int k = 0; k < 4; ++k) quat[k] = c.quat[k];
-        for (int jj = 0; jj < c.jn; ++jj) {
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {     // at most 3 joints per body (checked by the model compiler); unrolled so the
+          if (jj >= c.jn) break;             // table reads of joints 1, 2 are requested together, ahead of joint 0's arithmetic
           int jt, qa, da;
           v3 jp, ja;
           float q0;
@@ -421,7 +423,8 @@ struct Wave {
             st3(s_cdof + 6 * da, axis);        // raw, parent frame: axis ; anchor
             st3(s_cdof + 6 * da + 3, anchor);
             const float ang = (s_qpos[qa] - q0) * 0.5f;
-            const float sn = sinf(ang), cs = cosf(ang);
+            float sn, cs;
+            sincosf(ang, &sn, &cs);
             float ql[4] = {cs, ja.x * sn, ja.y * sn, ja.z * sn}, qn[4];
             quat_mul(qn, quat, ql);
 #pragma unroll
