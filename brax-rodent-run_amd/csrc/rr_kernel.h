@@ -225,8 +225,17 @@ __device__ __forceinline__ void kbi(float dt, float sr0, float sr1, const float*
   if (sr0 <= 0) k = -sr0 / (dmax * dmax);
   if (sr1 <= 0) b = -sr1 / dmax;
   float x = fabsf(pos) / width;
-  float a_ = (1.0f / powf(mid, power - 1.0f)) * powf(x, power);
-  float bb = 1.0f - (1.0f / powf(1.0f - mid, power - 1.0f)) * powf(1.0f - x, power);
+  float a_, bb;
+  if (power == 2.0f) {            // the exponent of every constraint of the rodent models: squares instead of four powf
+    a_ = (1.0f / mid) * (x * x);
+    bb = 1.0f - (1.0f / (1.0f - mid)) * ((1.0f - x) * (1.0f - x));
+  } else if (power == 1.0f) {
+    a_ = x;
+    bb = 1.0f - (1.0f - x);
+  } else {
+    a_ = (1.0f / powf(mid, power - 1.0f)) * powf(x, power);
+    bb = 1.0f - (1.0f / powf(1.0f - mid, power - 1.0f)) * powf(1.0f - x, power);
+  }
   float y = x < mid ? a_ : bb;
   imp = dmin + y * (dmax - dmin);
   imp = fminf(fmaxf(imp, dmin), dmax);
@@ -1582,7 +1591,9 @@ struct Wave {
           const float n = sqrtf(dot(w, w));
           v3 ax = mk3(0, 0, 0);
           if (n > RR_MINVAL) ax = w * (1.0f / n);
-          const float ang = D.dt * n, sn = sinf(ang * 0.5f), cs = cosf(ang * 0.5f);
+          const float ang = D.dt * n;
+          float sn, cs;
+          sincosf(ang * 0.5f, &sn, &cs);
           float qr[4] = {cs, ax.x * sn, ax.y * sn, ax.z * sn}, q0[4], qn[4];
           for (int k = 0; k < 4; ++k) q0[k] = s_qpos[qadr + k];
           quat_mul(qn, q0, qr);
