@@ -193,8 +193,11 @@ __device__ __forceinline__ float dpp_add(float v, const int ctrl_tag) {
     case 1: y = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true); break;    // quad_perm [2,3,0,1]
     case 2: y = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true); break;   // row_half_mirror
     case 3: y = __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true); break;   // row_mirror: every lane holds its row's sum
-    case 4: y = __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false); break;  // row_bcast15 -> rows 1, 3 add rows 0, 2
-    default: y = __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false); break; // row_bcast31 -> rows 2, 3 add rows 0+1
+    // the two row broadcasts as single DPP adds (the compiler emits v_mov_b32_dpp + v_add_f32 for the masked form):
+    // enabled rows add the broadcast lane, the other rows keep their value; s_nop covers the VALU-write -> DPP-read hazard
+    case 4: asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v)); return v;   // rows 1, 3 += rows 0, 2
+    case 5: asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v)); return v;   // rows 2, 3 += rows 0+1
+    default: return v;
   }
   return v + __int_as_float(y);
 }
