@@ -289,29 +289,17 @@ __device__ __forceinline__ BodyC load_bodyc(const RRTables& T, int b, int nbody)
 #ifndef RR_REP_SOLVE
 #define RR_REP_SOLVE 0
 #endif
-#ifndef RR_REP_FACTOR
-#define RR_REP_FACTOR 0
-#endif
 #ifndef RR_REP_LS
 #define RR_REP_LS 0
 #endif
 #ifndef RR_REP_UC
 #define RR_REP_UC 0
 #endif
-#ifndef RR_REP_MULM
-#define RR_REP_MULM 0
-#endif
 #ifndef RR_REP_JAC
 #define RR_REP_JAC 0
 #endif
-#ifndef RR_REP_LSEVAL
-#define RR_REP_LSEVAL 0
-#endif
 #ifndef RR_REP_MM
 #define RR_REP_MM 0
-#endif
-#ifndef RR_REP_INV
-#define RR_REP_INV 0
 #endif
 #ifndef RR_REP_KIN
 #define RR_REP_KIN 0
