@@ -21,3 +21,4 @@ tot=c.sum(1)
 print(f'N={N} envs, 10 substeps; cycles per env (median over envs): total {np.median(tot):.0f}')
 for i,n in enumerate(names):
     print(f'  {n:26s} {np.median(c[:,i]):10.0f} cyc  {100*np.median(c[:,i]/tot):5.1f} %')
+print('per-env total cycles: min %.0f  p10 %.0f  median %.0f  p90 %.0f  max %.0f  (launch time = slowest SIMD pair)' % (tot.min(), np.percentile(tot,10), np.median(tot), np.percentile(tot,90), tot.max()))
