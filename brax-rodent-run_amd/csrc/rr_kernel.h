@@ -246,6 +246,9 @@ __device__ __forceinline__ void kbi(float dt, float sr0, float sr1, const float*
 }
 
 struct LSPoint { float alpha, cost, d0, d1; };
+// a / b by v_rcp_f32 and one Newton step (<= 1 ulp from the IEEE quotient; the IEEE sequence is 13 instructions and the
+// line search, which sets the length of the slowest environments, does two per bracketing iteration)
+__device__ __forceinline__ float div_nr(float a, float b) { float r = __builtin_amdgcn_rcpf(b); r = r * (2.0f - b * r); return a * r; }
 
 // Table loads in the hot loops must be GLOBAL loads: when the optimiser loses the address space of a table pointer it
 // emits flat_load, which also counts on lgkmcnt -- every LDS wait would then drain the table prefetch as well.
@@ -1303,6 +1306,7 @@ struct Wave {
         const int ld = __builtin_amdgcn_readlane(leaf, l);
 #pragma unroll
         for (int s = 0; s < NVS; ++s) {
+          if (s > 0 && ld < RR_LANES * s) continue;      // wave-uniform: the chain (dofs <= leaf) has no dof in this slot
           const int d = lane + RR_LANES * s;
           if (d <= ld && ld <= (opaque(dofc1[s]) >> 16))
             qc[s] += cd[s][0] * w[0] + cd[s][1] * w[1] + cd[s][2] * w[2] + cd[s][3] * w[3] + cd[s][4] * w[4] + cd[s][5] * w[5];
@@ -1448,7 +1452,7 @@ struct Wave {
     LSPoint p0, lo, hi, tmp3[3];
     float a1[1] = {0.0f};
     ls_eval<1, true>(a1, qg, &p0, R, rjr, rjv, rD);
-    a1[0] = p0.alpha - p0.d0 / p0.d1;
+    a1[0] = p0.alpha - div_nr(p0.d0, p0.d1);
     ls_eval<1, false>(a1, qg, &lo, R, rjr, rjv, rD);
     if (lo.d0 < p0.d0) { hi = p0; } else { hi = lo; lo = p0; }
     stamp<PROF>(18);
@@ -1458,7 +1462,7 @@ struct Wave {
       done |= (lo.d0 < 0) && (lo.d0 > -gtol);
       done |= (hi.d0 > 0) && (hi.d0 < gtol);
       if (uni(done)) break;
-      const float a3[3] = {lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, 0.5f * (lo.alpha + hi.alpha)};
+      const float a3[3] = {lo.alpha - div_nr(lo.d0, lo.d1), hi.alpha - div_nr(hi.d0, hi.d1), 0.5f * (lo.alpha + hi.alpha)};
       ls_eval<3, false>(a3, qg, tmp3, R, rjr, rjv, rD);
       const LSPoint lo_next = tmp3[0], hi_next = tmp3[1], mid = tmp3[2];
       const bool swap_lo_next = (lo.d0 > 0) || (lo.d0 < lo_next.d0);

@@ -22,3 +22,9 @@ print(f'N={N} envs, 10 substeps; cycles per env (median over envs): total {np.me
 for i,n in enumerate(names):
     print(f'  {n:26s} {np.median(c[:,i]):10.0f} cyc  {100*np.median(c[:,i]/tot):5.1f} %')
 print('per-env total cycles: min %.0f  p10 %.0f  median %.0f  p90 %.0f  max %.0f  (launch time = slowest SIMD pair)' % (tot.min(), np.percentile(tot,10), np.median(tot), np.percentile(tot,90), tot.max()))
+order = np.argsort(tot)
+slow, mid = order[-N // 20:], order[N // 2 - N // 40:N // 2 + N // 40]
+print('slowest 5 %% of the envs vs the median 5 %%, cycles per phase (the launch lasts as long as the slowest env):')
+for i, n in enumerate(names):
+    if c[:, i].max() > 0:
+        print(f'  {n:26s} slow {c[slow, i].mean():10.0f}   median {c[mid, i].mean():10.0f}   diff {c[slow, i].mean() - c[mid, i].mean():+10.0f}')
