@@ -237,7 +237,7 @@ extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t devi
   if ((rc = upload_levels(b, "k_factor3", &b->T.factor3)) || (rc = upload_levels(b, "k_linv", &b->T.linv))) { rr_batch_destroy(b); return rc; }
   kern_t kern = pick_kernel(m);
   if (!m->stage_ok) { rr_batch_destroy(b); return fail(RR_EUNSUPPORTED, "rr_batch_create: 4*ncon + nv exceeds the line-search staging cells (6*nbody)"); }
-  if (m->dims.lds_bytes > 64 * 1024) { rr_batch_destroy(b); return fail(RR_EUNSUPPORTED, "rr_batch_create: per-env working set exceeds 160 KiB LDS"); }
+  if (m->dims.lds_bytes > 64 * 1024) { rr_batch_destroy(b); return fail(RR_EUNSUPPORTED, "rr_batch_create: per-env working set exceeds the 64 KiB of LDS one workgroup may address"); }
   for (kern_t kk : {kern, pick_kernel(m, false, true)}) {   // production and debug-dump instances
     hipError_t e = hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, m->dims.lds_bytes);
     if (e != hipSuccess) { rr_batch_destroy(b); return fail(RR_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }

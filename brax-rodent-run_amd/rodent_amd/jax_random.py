@@ -5,7 +5,7 @@ vectorised over a leading batch of keys so one call seeds all environments (the 
 `reset` over `split(key_env, num_envs)`).
 
 Pinned by the known-answer vector in the reference notebook [NB Env_step.ipynb:1612-1630]
-(tests/test_jax_random.py).
+(tests/test_known_answers.py).
 """
 from __future__ import annotations
 
@@ -44,8 +44,12 @@ def PRNGKey(seed: int) -> np.ndarray:
 def random_bits(key, n: int) -> np.ndarray:
     """32-bit random words: key [..., 2] -> [..., n] (jax `_threefry_random_bits`, non-partitionable)."""
     key = np.asarray(key, dtype=np.uint32)
-    m = n + (n % 2)
-    cnt = np.arange(m, dtype=np.uint32)
+    # jax `threefry_2x32`: an odd-sized counter array is padded with a literal 0 (not with the next counter) before it is
+    # split into halves, and the padded output word is dropped
+    cnt = np.arange(n, dtype=np.uint32)
+    if n % 2:
+        cnt = np.concatenate([cnt, np.zeros(1, np.uint32)])
+    m = cnt.size
     x0, x1 = cnt[: m // 2], cnt[m // 2:]
     k0, k1 = key[..., 0:1], key[..., 1:2]
     y0, y1 = threefry2x32(k0, k1, x0, x1)

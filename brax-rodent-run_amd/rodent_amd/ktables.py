@@ -1,6 +1,6 @@
 """Kernel schedule tables: lane-major index tables for the one-wave-per-env HIP step kernel.
 
-The fused step kernel (csrc/rr_step.hip) runs one 64-lane wavefront per environment.  All of
+The fused step kernel (csrc/rr_kernel.h) runs one 64-lane wavefront per environment.  All of
 its irregular access patterns (kinematic-tree level sweeps, sparse L'DL factor/solve, sparse
 M*x, contact-Jacobian transpose products) are driven by static index tables computed here once
 per model and stored in the model blob as `k_*` arrays.  Tables indexed by a loop iteration `t`

@@ -14,7 +14,7 @@ and the `mj_setConst` constants (`dof_invweight0`, `body_invweight0`, `stat.mean
 The MuJoCo behaviour restated here is from the public MuJoCo documentation
 (XML reference, "Computation" chapter); the MuJoCo sources are not in the
 reference tree, so this is pinned only by the known-answer data in the reference's
-notebooks (tests/test_mjcf_compile.py).
+notebooks (tests/test_known_answers.py, tests/test_ktables.py).
 """
 from __future__ import annotations
 

@@ -2,7 +2,7 @@
 
 Tolerances are float32 round-off scaled: the oracle runs in float64; per-stage fields of ONE forward
 pass from identical inputs must agree to ~1e-4 of the field's scale (1e-5 for the pure-kinematics
-fields); integer indices are bit-exact (tests/test_mjcf_compile.py pins the contact id list).
+fields); integer indices are bit-exact (tests/test_known_answers.py pins the contact id list).
 """
 import numpy as np
 import pytest
