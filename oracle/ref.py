@@ -45,6 +45,10 @@ def _lib(precision: str):
         lib.ref_env_step.argtypes = [C.c_void_p, C.c_void_p, dp, C.c_int, dp, C.c_int, C.POINTER(C.c_int),
                                      C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, dp, dp, dp, dp]
         lib.ref_step_batch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), dp, C.c_int, C.c_int]
+        lib.ref_env_step_batch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), dp, C.c_int, C.c_int, dp, C.c_int, C.POINTER(C.c_int),
+                                           C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, dp, dp, dp, dp]
+        lib.ref_sig_reset.argtypes = [C.c_void_p]
+        lib.ref_sig_get.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         _LIBS[precision] = lib
     return _LIBS[precision]
 
@@ -108,6 +112,16 @@ class RefData:
         if n < 0:
             raise KeyError(name)
 
+    def sig_reset(self):
+        self.lib.ref_sig_reset(self.h)
+
+    def sig(self):
+        """(hash of the contact/limit active sets of every forward pass since sig_reset, hash of the solver's final row
+        states, summed CG iterations, number of forward passes): the discrete decisions a trajectory took."""
+        out = (C.c_uint64 * 4)()
+        self.lib.ref_sig_get(self.h, out)
+        return int(out[0]), int(out[1]), int(out[2]), int(out[3])
+
     def obs(self, track_pos, cur_frame):
         tp = np.ascontiguousarray(track_pos, np.float64)
         out = np.zeros(self.m.obs_dim, np.float64)
@@ -133,3 +147,51 @@ def step_batch(model: RefModel, datas, ctrl, n_frames=10):
     ctrl = np.ascontiguousarray(ctrl, np.float64)
     arr = (C.c_void_p * len(datas))(*[d.h for d in datas])
     model.lib.ref_step_batch(model.h, arr, _dp(ctrl), len(datas), n_frames)
+
+
+class RefBatch:
+    """N oracle environments stepped together (OpenMP over envs): the CPU counterpart of `Rodent` for the long parity runs."""
+    STATE = ("qpos", "qvel", "act", "qacc_warmstart")
+
+    def __init__(self, model: RefModel, n: int):
+        self.m, self.n = model, n
+        self.d = [RefData(model) for _ in range(n)]
+        self._arr = (C.c_void_p * n)(*[d.h for d in self.d])
+
+    def init(self, qpos, qvel):
+        for e, d in enumerate(self.d):
+            d.init(qpos[e], qvel[e])
+
+    def get(self, name):
+        return np.stack([d.get(name) for d in self.d])
+
+    def set_state(self, st, envs=None):
+        for e in (range(self.n) if envs is None else envs):
+            for k in self.STATE:
+                self.d[e].set(k, st[k][e])
+
+    def state(self):
+        return {k: self.get(k) for k in self.STATE}
+
+    def obs(self, track_pos, cur_frame):
+        return np.stack([d.obs(track_pos, int(cur_frame[e])) for e, d in enumerate(self.d)])
+
+    def sig_reset(self):
+        for d in self.d:
+            d.sig_reset()
+
+    def sigs(self):
+        return [d.sig() for d in self.d]
+
+    def env_step(self, action, track_pos, cur_frame, n_frames=10, healthy_reward=1.0, ctrl_cost_weight=0.1,
+                 healthy_z_range=(0.03, 0.5), terminate_when_unhealthy=True):
+        """-> obs [N, obs_dim], reward [N], done [N], cur_frame [N] (int32, new), metrics [N, 3]"""
+        m, n = self.m, self.n
+        action = np.ascontiguousarray(action, np.float64).reshape(n, m.nu)
+        tp = np.ascontiguousarray(track_pos, np.float64)
+        cf = np.ascontiguousarray(cur_frame, np.int32).copy()
+        obs = np.zeros((n, m.obs_dim)); rew = np.zeros(n); done = np.zeros(n); met = np.zeros((n, 3))
+        m.lib.ref_env_step_batch(m.h, self._arr, _dp(action), n, n_frames, _dp(tp), tp.shape[0],
+                                 cf.ctypes.data_as(C.POINTER(C.c_int)), healthy_reward, ctrl_cost_weight, healthy_z_range[0],
+                                 healthy_z_range[1], int(terminate_when_unhealthy), _dp(obs), _dp(rew), _dp(done), _dp(met))
+        return obs, rew, done, cf, met

@@ -97,6 +97,13 @@ static real* rtab(const ref_model* m, const char* name) {
   return out;
 }
 
+static void unit_n(real* v, int n) {
+  real s = 0;
+  for (int i = 0; i < n; i++) s += v[i] * v[i];
+  s = SQRT(s);
+  if (s > MINVAL) for (int i = 0; i < n; i++) v[i] /= s;
+}
+
 ref_model* ref_model_load(const char* path) {
   FILE* f = fopen(path, "rb");
   if (!f) return NULL;
@@ -146,6 +153,12 @@ ref_model* ref_model_load(const char* path) {
   RT(dof_armature); RT(dof_damping); RT(dof_invweight0); RT(qpos0); RT(qpos_spring);
   RT(geom_pos); RT(geom_quat); RT(geom_size);
   RT(con_friction); RT(con_solref); RT(con_solimp); RT(con_invweight);
+  /* unit quaternions / axes are unit only to float32 round-off in the blob: renormalise them in the oracle's arithmetic
+   * (MuJoCo normalises them in double at compile time), so that formulations that treat a non-unit vector differently
+   * (oracle/np_ref.py) agree to double round-off */
+  for (int b = 0; b < m->nbody; b++) { unit_n(m->body_quat + 4 * b, 4); unit_n(m->body_iquat + 4 * b, 4); }
+  for (int g = 0; g < m->ngeom; g++) unit_n(m->geom_quat + 4 * g, 4);
+  for (int j = 0; j < m->njnt; j++) unit_n(m->jnt_axis + 3 * j, 3);
   m->gain0 = rtab(m, "actuator_gainprm0"); m->biasprm = rtab(m, "actuator_biasprm");
   m->tau = rtab(m, "actuator_dynprm0"); m->ctrlrange = rtab(m, "actuator_ctrlrange");
   return m;
@@ -175,6 +188,11 @@ typedef struct ref_data {
   real *Jaref, *Ma, *grad, *Mgrad, *search, *mv, *jv, *tmpv, *quad;
   int solver_niter;
   real solver_cost;
+  /* bookkeeping for the parity tests: which discrete decisions the trajectory took since the last ref_sig_reset */
+  uint64_t sig_active;  /* FNV-1a over every forward pass's contact (dist < 0) and limit (pos < 0) bit patterns */
+  uint64_t sig_rows;    /* same over the solver's final row states (Jaref < 0) */
+  long niter_sum;       /* CG iterations summed over the forward passes */
+  long nforward;
 } ref_data;
 
 static real* ralloc(size_t n) { return (real*)calloc(n ? n : 1, sizeof(real)); }
@@ -200,6 +218,7 @@ ref_data* ref_data_new(const ref_model* m) {
   d->mv = ralloc(nv); d->jv = ralloc(m->nefc); d->tmpv = ralloc(nv); d->quad = ralloc(3 * (size_t)m->nefc);
   for (int i = 0; i < m->nq; i++) d->qpos[i] = m->qpos0[i];
   d->xquat[0] = 1; d->xmat[0] = d->xmat[4] = d->xmat[8] = 1;
+  d->sig_active = d->sig_rows = 1469598103934665603ULL;
   return d;
 }
 
@@ -841,7 +860,15 @@ void ref_forward(const ref_model* m, ref_data* d) {
   fwd_actuation(m, d);
   fwd_acceleration(m, d);
   solve(m, d);
+  for (int r = 0; r < m->nefc; r++) {
+    d->sig_active = (d->sig_active ^ (uint64_t)(d->efc_pos[r] < 0)) * 1099511628211ULL;
+    d->sig_rows = (d->sig_rows ^ (uint64_t)(d->Jaref[r] < 0)) * 1099511628211ULL;
+  }
+  d->niter_sum += d->solver_niter;
+  d->nforward += 1;
 }
+void ref_sig_reset(ref_data* d) { d->sig_active = d->sig_rows = 1469598103934665603ULL; d->niter_sum = 0; d->nforward = 0; }
+void ref_sig_get(const ref_data* d, uint64_t* out /*[4]*/) { out[0] = d->sig_active; out[1] = d->sig_rows; out[2] = (uint64_t)d->niter_sum; out[3] = (uint64_t)d->nforward; }
 
 /* A-8 [UP mjx forward.euler/_advance] */
 static void euler(const ref_model* m, ref_data* d) {
@@ -983,7 +1010,15 @@ void ref_env_step(const ref_model* m, ref_data* d, const double* action, int n_f
   metrics[0] = (double)pos_reward; metrics[1] = (double)-cc; metrics[2] = (double)hr;
 }
 
-/* ------------------------------------------------------------------ batched helpers (cpu_baseline timing) */
+/* ------------------------------------------------------------------ batched helpers (cpu_baseline timing, long parity runs) */
+void ref_env_step_batch(const ref_model* m, ref_data** ds, const double* action /*[N][nu]*/, int N, int n_frames, const double* track_pos, int T,
+                        int* cur_frame /*[N]*/, double healthy_reward, double ctrl_cost_weight, double min_z, double max_z,
+                        int terminate_when_unhealthy, double* obs /*[N][obs_dim]*/, double* reward, double* done, double* metrics /*[N][3]*/) {
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int e = 0; e < N; e++)
+    ref_env_step(m, ds[e], action + (size_t)e * m->nu, n_frames, track_pos, T, cur_frame + e, healthy_reward, ctrl_cost_weight, min_z, max_z,
+                 terminate_when_unhealthy, obs + (size_t)e * m->obs_dim, reward + e, done + e, metrics + 3 * (size_t)e);
+}
 void ref_step_batch(const ref_model* m, ref_data** ds, const double* ctrl /*[N][nu]*/, int N, int n_frames) {
 #pragma omp parallel for schedule(dynamic, 4)
   for (int e = 0; e < N; e++) ref_step(m, ds[e], ctrl + (size_t)e * m->nu, n_frames);
