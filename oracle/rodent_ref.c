@@ -560,7 +560,11 @@ static void kbi(const ref_model* m, const real* solref, const real* solimp, real
   real mid = FMIN(FMAX(solimp[3], MINIMP), MAXIMP);
   real power = FMAX(R(1.0), solimp[4]);
   real k = 1 / (dmax * dmax * timeconst * timeconst * dampratio * dampratio);
+#ifdef REF_BUG   /* deliberate modelling error for tests/test_parity_criteria.py: 5 % too much constraint damping */
+  real b = R(2.1) / (dmax * timeconst);
+#else
   real b = 2 / (dmax * timeconst);
+#endif
   if (solref[0] <= 0) k = -solref[0] / (dmax * dmax);
   if (solref[1] <= 0) b = -solref[1] / dmax;
   real x = FABS(pos) / width;

@@ -1,0 +1,202 @@
+"""Parity ladder: harness and criteria shared by the CPU validation of the criteria (tests/test_parity_criteria.py) and
+the GPU tests (tests/test_gpu_ladder.py).
+
+Why teacher forcing.  North star: "qpos/qvel within 1e-5 rel after 1000 steps".  Free-running float32 and float64
+evaluations of THIS map separate much faster than that, whoever computes them: the truncated (8-iteration) CG solve with
+its branchy line search turns a double round-off difference into 1e-2 within 100 substeps (tests/test_np_ref.py), and even
+the converged map, driven by fresh U(-1,1) actions, takes the scalar float32 oracle 3e-2 away from float64 in 10 env-steps.
+What can be asserted tightly over 1000 steps is the ONE-STEP map: every step starts from the float64 oracle's state
+(rounded to float32) and its result is compared with the oracle's -- integers exactly, reals by the criteria below.
+
+Criteria (fixed before the GPU run; validated on the CPU with a second float32 build of the oracle that rounds
+differently -- FMA contraction -- which must pass, and a build with a deliberate 5 % modelling error, which must fail):
+  C1  discrete decisions: every contact's / limit's activity bit equals the float64 oracle's unless the float64
+      distance is within `edge` of the switching point (a float32 evaluation may legitimately land on the other side).
+  C2  solver iteration count equal in >= 90 % of the samples (a CG run stops on two float thresholds).
+  C3  error quantiles: Q_q(err) <= 3 * Q_q(gap) + floor for q in (0.5, 0.9, 0.99), err = |impl - f64|,
+      gap = |scalar float32 oracle - f64| on the same inputs.  No per-sample bound against the sample's own gap: err and
+      gap are two draws from one heavy-tailed distribution.
+"""
+import numpy as np
+
+from oracle import ref
+from rodent_amd import assets, mjcf
+
+STATE = ("qpos", "qvel", "act", "qacc_warmstart")
+
+
+def f32r(x):
+    return np.asarray(x, np.float64).astype(np.float32).astype(np.float64)
+
+
+class OracleImpl:
+    """One substep / env step of a RefBatch in the given precision, in the harness' calling convention."""
+
+    def __init__(self, model_name, n, precision, iterations):
+        self.M = ref.RefModel(assets.asset_path(model_name), precision)
+        self.M.set_iterations(*iterations)
+        self.b = ref.RefBatch(self.M, n)
+        self.n = n
+        tab = mjcf.load_blob(assets.asset_path(model_name))
+        self.lim_dof = tab["jnt_dofadr"][tab["limit_jnt"]]
+
+    def substep(self, st, ctrl):
+        self.b.set_state(st)
+        ref.step_batch(self.M, self.b.d, ctrl, 1)
+        out = self.b.state()                                    # qacc_warmstart IS the solver's qacc
+        out["con_dist"] = self.b.get("con_dist")
+        pos = self.b.get("efc_pos")[:, :self.M.nlimit]
+        out["lim_pos"] = pos
+        out["lim_D"] = self.b.get("efc_D")[:, :self.M.nlimit]
+        out["lim_aref"] = self.b.get("efc_aref")[:, :self.M.nlimit]
+        out["niter"] = self.b.get("solver_niter")[:, 0].astype(int)
+        return out
+
+
+def rollout_inputs(model_name, n, steps, iterations, seed, n_frames=1, reset_every=None, z_range=(0.03, 0.5)):
+    """The float64 oracle's own trajectory under fresh U(-1,1) actions: the list of (state, ctrl) every implementation is
+    started from.  Envs that leave the healthy range (or `reset_every` steps) restart from their initial state."""
+    from tests import util
+    st0, M, tab = util.settled_states(ref, model_name, n, seed=seed, iterations=iterations)
+    st0 = {k: f32r(v) for k, v in st0.items()}
+    A = OracleImpl(model_name, n, "f64", iterations)
+    rng = np.random.default_rng(seed + 1)
+    st = {k: v.copy() for k, v in st0.items()}
+    age = np.zeros(n, int)
+    seq = []
+    for t in range(steps):
+        ctrl = f32r(rng.uniform(-1, 1, (n, M.nu)))
+        seq.append(({k: v.copy() for k, v in st.items()}, ctrl))
+        A.b.set_state(st)
+        ref.step_batch(A.M, A.b.d, ctrl, n_frames)              # OpenMP over envs
+        nxt = A.b.state()
+        age += 1
+        bad = ~np.isfinite(nxt["qpos"]).all(1) | (nxt["qpos"][:, 2] < z_range[0]) | (nxt["qpos"][:, 2] > z_range[1])
+        if reset_every:
+            bad |= age >= reset_every
+        for k in STATE:
+            nxt[k][bad] = st0[k][bad]
+        age[bad] = 0
+        st = {k: f32r(v) for k, v in nxt.items()}
+    return seq, A, tab
+
+
+def quantile_rows(name, err, gap, qs=(0.5, 0.9, 0.99)):
+    return [(name, q, float(np.quantile(err, q)), float(np.quantile(gap, q))) for q in qs]
+
+
+def check_quantiles(rows, floors, factor=3.0):
+    """C3.  rows from quantile_rows; floors: name -> absolute floor."""
+    bad = [(n, q, e, g) for n, q, e, g in rows if not e <= factor * g + floors[n]]
+    assert not bad, ("error quantiles above %g x the scalar float32 oracle's" % factor, bad)
+
+
+def check_activity(got, want, edge, what):
+    """C1.  got / want: signed distances [.., k]; the sign must agree unless |want| < edge."""
+    flip = ((got < 0) != (want < 0)) & (np.abs(want) >= edge)
+    assert not flip.any(), (what, "activity differs away from the switching point", np.argwhere(flip)[:5], want[flip][:5], got[flip][:5])
+    return float(((got < 0) != (want < 0)).mean())
+
+
+def substep_ladder(impl, seq, A, gap_impl, report=None):
+    """Teacher-forced substeps: returns the criteria inputs.  `impl.substep(state, ctrl)` -> dict with the state fields,
+    con_dist, lim_pos, lim_D, lim_aref, niter."""
+    rows = {k: [] for k in ("qpos", "qvel", "qacc", "act")}
+    gaps = {k: [] for k in rows}
+    niter_eq, niter_eq_gap, n_samples = 0, 0, 0
+    edge_flips = 0.0
+    lim_err = {"lim_D": 0.0, "lim_aref": 0.0}
+    for st, ctrl in seq:
+        want = A.substep(st, ctrl)
+        got = impl.substep(st, ctrl)
+        gp = gap_impl.substep(st, ctrl)
+        assert np.isfinite(got["qpos"]).all() and np.isfinite(got["qvel"]).all()
+        edge_flips += check_activity(got["con_dist"], want["con_dist"], 2e-6, "contact")
+        edge_flips += check_activity(got["lim_pos"], want["lim_pos"], 2e-6, "limit")
+        act = want["lim_pos"] < -2e-6                               # rows that exist in both evaluations
+        for k in lim_err:
+            if act.any():
+                lim_err[k] = max(lim_err[k], float((np.abs(got[k] - want[k])[act] / np.maximum(np.abs(want[k][act]), 1e-6)).max()))
+        niter_eq += int((got["niter"] == want["niter"]).sum())
+        niter_eq_gap += int((gp["niter"] == want["niter"]).sum())
+        n_samples += len(want["niter"])
+        for k, f in (("qpos", "qpos"), ("qvel", "qvel"), ("qacc", "qacc_warmstart"), ("act", "act")):
+            scale = np.maximum(np.abs(want[f]).max(1), 1.0) if k == "qacc" else 1.0
+            rows[k].append(np.abs(got[f] - want[f]).max(1) / scale)
+            gaps[k].append(np.abs(gp[f] - want[f]).max(1) / scale)
+    out = dict(niter_equal=niter_eq / n_samples, niter_equal_f32_oracle=niter_eq_gap / n_samples, samples=n_samples,
+               activity_flips_at_edge=edge_flips / (2 * len(seq)), limit_rows=lim_err, quantiles=[])
+    for k in rows:
+        out["quantiles"] += quantile_rows(k, np.concatenate(rows[k]), np.concatenate(gaps[k]))
+    if report is not None:
+        report.update(out)
+    return out
+
+
+SUBSTEP_FLOORS = dict(qpos=2e-7, qvel=2e-5, qacc=2e-6, act=1e-7)     # absolute; a few float32 ulps of the quantity's scale
+
+
+def assert_substep_criteria(out):
+    check_quantiles(out["quantiles"], SUBSTEP_FLOORS)
+    assert out["niter_equal"] >= 0.90, out["niter_equal"]
+    assert out["limit_rows"]["lim_D"] < 1e-3 and out["limit_rows"]["lim_aref"] < 1e-3, out["limit_rows"]
+
+
+# ------------------------------------------------------------------------------------------ env-step level
+def obs_segments(tab):
+    nq, nv, nb = int(tab["nq"]), int(tab["nv"]), int(tab["nbody"])
+    o, seg = 0, {}
+    for name, w in (("qpos", nq), ("qvel", nv), ("cinert", 10 * (nb - 1)), ("cvel", 6 * (nb - 1)), ("qfrc_actuator", nv), ("track_local", 3)):
+        seg[name] = slice(o, o + w)
+        o += w
+    assert o == int(tab["obs_dim"])
+    return seg
+
+
+class OracleEnvImpl(OracleImpl):
+    def __init__(self, model_name, n, precision, iterations, track, z_range=(0.03, 0.5)):
+        super().__init__(model_name, n, precision, iterations)
+        self.track, self.z = np.asarray(track, np.float64), z_range
+
+    def env_step(self, st, ctrl, cur_frame):
+        self.b.set_state(st)
+        obs, rew, done, cf, met = self.b.env_step(ctrl, self.track, cur_frame, 10, healthy_z_range=self.z)
+        out = self.b.state()
+        out.update(obs=obs, reward=rew, done=done, cur_frame=cf, metrics=met)
+        return out
+
+
+ENV_FLOORS = dict(qpos=2e-6, qvel=2e-4, obs_cinert=1e-7, obs_cvel=2e-4, obs_qfrc_actuator=1e-6, obs_track_local=2e-6, reward=2e-6)
+
+
+def envstep_ladder(impl, seq_states, A, gap_impl, tab, z_range=(0.03, 0.5)):
+    """Teacher-forced ENV steps (10 substeps + reward/done/obs epilogue).  seq_states: list of (state, ctrl, cur_frame)."""
+    seg = obs_segments(tab)
+    names = ["qpos", "qvel", "reward"] + [f"obs_{k}" for k in ("cinert", "cvel", "qfrc_actuator", "track_local")]
+    rows, gaps = {k: [] for k in names}, {k: [] for k in names}
+    done_mismatch_near_threshold = 0
+    for st, ctrl, cf in seq_states:
+        want, got, gp = A.env_step(st, ctrl, cf), impl.env_step(st, ctrl, cf), gap_impl.env_step(st, ctrl, cf)
+        assert np.array_equal(got["cur_frame"], want["cur_frame"])                       # integer bookkeeping: exact
+        z = want["qpos"][:, 2]
+        near = (np.abs(z - z_range[0]) < 1e-3) | (np.abs(z - z_range[1]) < 1e-3)
+        dm = got["done"] != want["done"]
+        assert not (dm & ~near).any(), ("done differs away from the height threshold", z[dm])
+        done_mismatch_near_threshold += int(dm.sum())
+        # obs = [qpos, qvel] of the stepped state: the obs entries must BE the state entries
+        assert np.array_equal(np.asarray(got["obs"][:, seg["qpos"]], np.float32), np.asarray(got["qpos"], np.float32))
+        assert np.array_equal(np.asarray(got["obs"][:, seg["qvel"]], np.float32), np.asarray(got["qvel"], np.float32))
+        for k in names:
+            if k.startswith("obs_"):
+                s = seg[k[4:]]
+                e, g = np.abs(got["obs"][:, s] - want["obs"][:, s]), np.abs(gp["obs"][:, s] - want["obs"][:, s])
+                sc = np.maximum(np.abs(want["obs"][:, s]).max(1), 1e-3) if k == "obs_cinert" else 1.0
+                rows[k].append(e.max(1) / sc); gaps[k].append(g.max(1) / sc)
+            elif k == "reward":
+                rows[k].append(np.abs(got["reward"] - want["reward"])); gaps[k].append(np.abs(gp["reward"] - want["reward"]))
+            else:
+                rows[k].append(np.abs(got[k] - want[k]).max(1)); gaps[k].append(np.abs(gp[k] - want[k]).max(1))
+    out = dict(samples=len(seq_states) * len(seq_states[0][2]), done_mismatch_near_threshold=done_mismatch_near_threshold, quantiles=[])
+    for k in names:
+        out["quantiles"] += quantile_rows(k, np.concatenate(rows[k]), np.concatenate(gaps[k]), qs=(0.5, 0.9))
+    return out

@@ -1,0 +1,184 @@
+"""GPU parity ladder (tests/parity.py explains the design): the HIP kernel through the C ABI against the float64 oracle,
+
+  1. 1000 teacher-forced SUBSTEPS at the launcher's CG 8/8 (debug-dump instance): contact / limit activity bits and limit
+     rows against the oracle, iteration counts, error quantiles of qpos / qvel / qacc against the scalar float32 oracle's;
+  2. the same inputs through the PRODUCTION instance (what bench.py times);
+  3. 1000 teacher-forced ENV steps through `Rodent.step` (production instance): cur_frame / done exact, every observation
+     segment, reward;
+  4. a free-running 1000-step rollout with a CONVERGED solver (50/50) through Episode(150)+AutoReset against the oracle
+     env: integer bookkeeping, restored first states, and the divergence curve (reported; asserted over the first 10 steps);
+  5. the np_ref fixtures (tests/golden/step_*.npz): numbers that never passed through oracle/rodent_ref.c;
+  6. `Rodent.reset`: observation segments and qacc_warmstart against the oracle's init.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import parity, util
+from tests.hip_impl import HipEnvImpl, HipImpl, NoDiscrete
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def _report(name, obj):
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, f"ladder_{name}.json"), "w") as f:
+        json.dump(obj, f, indent=1, default=float)
+    print(name, json.dumps(obj, default=float))
+
+
+@pytest.fixture(scope="module")
+def substep_inputs(oracle_built):
+    return parity.rollout_inputs("rodent_optimized", 16, 1000, (8, 8), seed=31)
+
+
+def test_teacher_forced_1000_substeps_debug_instance(substep_inputs):
+    seq, A, tab = substep_inputs
+    out = parity.substep_ladder(HipImpl("rodent_optimized", 16, (8, 8), True), seq, A, parity.OracleImpl("rodent_optimized", 16, "f32", (8, 8)))
+    _report("substeps_cg8_debug", out)
+    parity.assert_substep_criteria(out)
+
+
+def test_teacher_forced_1000_substeps_production_instance(substep_inputs):
+    seq, A, tab = substep_inputs
+    out = parity.substep_ladder(NoDiscrete(HipImpl("rodent_optimized", 16, (8, 8), False), A), seq, A,
+                                parity.OracleImpl("rodent_optimized", 16, "f32", (8, 8)))
+    _report("substeps_cg8_production", out)
+    parity.check_quantiles(out["quantiles"], parity.SUBSTEP_FLOORS)
+
+
+def test_teacher_forced_substeps_rodent_pair(oracle_built):
+    seq, A, tab = parity.rollout_inputs("rodent_pair", 8, 200, (8, 8), seed=33)
+    out = parity.substep_ladder(HipImpl("rodent_pair", 8, (8, 8), True), seq, A, parity.OracleImpl("rodent_pair", 8, "f32", (8, 8)))
+    _report("substeps_cg8_pair", out)
+    parity.assert_substep_criteria(out)
+
+
+def test_teacher_forced_1000_env_steps(oracle_built):
+    N, T = 16, 1000
+    track = util.synthetic_track()
+    seq, A0, tab = parity.rollout_inputs("rodent_optimized", N, T, (8, 8), seed=35, n_frames=10, reset_every=150)
+    rng = np.random.default_rng(36)
+    seq = [(st, ctrl, rng.integers(0, 260, N).astype(np.int32)) for st, ctrl in seq]      # incl. frames beyond the clip (saturation)
+    A = parity.OracleEnvImpl("rodent_optimized", N, "f64", (8, 8), track)
+    out = parity.envstep_ladder(HipEnvImpl(N, (8, 8), track), seq, A, parity.OracleEnvImpl("rodent_optimized", N, "f32", (8, 8), track), tab)
+    _report("envsteps_cg8", out)
+    parity.check_quantiles(out["quantiles"], parity.ENV_FLOORS)
+
+
+def test_free_running_converged_solver_1000_steps(oracle_built):
+    """HIP rollout through wrappers.wrap(episode_length=150) vs the oracle env (float64, and float32 for the gap), solver
+    50/50, same reset keys and actions.  Asserted: integer bookkeeping (cur_frame, steps, truncation) exact for all 1000
+    steps; `done` equal while an env's trajectory has not separated; the state restored at an episode end is bit-identical
+    to the first state; error quantiles over the first 10 steps within 3x the float32 oracle's.  Reported: the divergence
+    curve to 1000 steps (profiles/r02_parity_ladder.json)."""
+    from rodent_amd import envs, jax_random
+    from rodent_amd.envs import wrappers
+    from tests.oracle_env import OracleRodent
+    N, T, EP = 32, 1000, 150
+    track = util.synthetic_track()
+    env = envs.get_environment("rodent", track_pos=track, num_envs=N, xml_path="rodent_optimized.xml", iterations=50, ls_iterations=50, device=DEV)
+    wenv = wrappers.wrap(env, episode_length=EP, action_repeat=1)
+    keys = jax_random.split(jax_random.PRNGKey(5), N)
+    hs = wenv.reset(keys)
+    A = OracleRodent("rodent_optimized", N, "f64", (50, 50), track, EP)
+    B = OracleRodent("rodent_optimized", N, "f32", (50, 50), track, EP)
+    A.reset(keys); B.reset(keys)
+    first_qpos = hs.pipeline_state.qpos.clone()
+    np.testing.assert_array_equal(hs.info["cur_frame"].cpu().numpy(), A.cur_frame)
+    rng = np.random.default_rng(6)
+    insync = np.ones(N, bool)
+    curve, early = [], {"err": [], "gap": []}
+    marks = {1, 2, 5, 10, 20, 50, 100, 149, 150, 151, 300, 500, 1000}
+    for t in range(1, T + 1):
+        a = parity.f32r(rng.uniform(-1, 1, (N, 30)))
+        hs = wenv.step(hs, torch.tensor(a, dtype=torch.float32, device=DEV))
+        A.step(a); B.step(a)
+        hq = hs.pipeline_state.qpos.cpu().numpy().astype(np.float64)
+        assert np.isfinite(hq).all() and torch.isfinite(hs.obs).all()
+        np.testing.assert_array_equal(hs.info["cur_frame"].cpu().numpy(), A.cur_frame)          # never restored, saturating index
+        np.testing.assert_array_equal(hs.info["steps"].cpu().numpy(), A.steps)
+        hd = hs.done.cpu().numpy()
+        insync &= hd == A.done
+        np.testing.assert_array_equal(hs.info["truncation"].cpu().numpy()[insync], A.truncation[insync])
+        ended = np.nonzero(hd)[0]
+        if len(ended):                                                                             # AutoReset: bit-identical first state
+            assert torch.equal(hs.pipeline_state.qpos[ended], first_qpos[ended])
+        err = np.abs(hq - A.state()["qpos"]).max(1)
+        gap = np.abs(B.state()["qpos"] - A.state()["qpos"]).max(1)
+        if t <= 10:
+            early["err"].append(err); early["gap"].append(gap)
+        if t in marks:
+            curve.append(dict(step=t, insync=int(insync.sum()), err_median=float(np.median(err)), err_max=float(err.max()),
+                              f32_oracle_median=float(np.median(gap)), f32_oracle_max=float(gap.max())))
+    rows = []
+    for i in range(10):
+        rows += parity.quantile_rows(f"qpos@{i + 1}", early["err"][i], early["gap"][i], qs=(0.5, 0.9))
+    _report("free_running_cg50", dict(curve=curve, early=rows))
+    parity.check_quantiles(rows, {f"qpos@{i + 1}": 2e-6 for i in range(10)})
+
+
+@pytest.mark.parametrize("model_name", ["rodent_optimized", "rodent_pair"])
+def test_np_ref_fixtures(model_name):
+    """HIP against tests/golden/step_*.npz, generated by oracle/np_ref.py alone (tools/make_step_golden.py)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"step_{model_name}.npz"))
+    n = g["in_qpos"].shape[0]
+    st = {k: g[f"in_{k}"] for k in parity.STATE}
+    impl = HipImpl(model_name, n, (8, 8), True)
+    ds = impl._dev(st)
+    impl.batch.pipeline_step(ds, torch.tensor(g["in_ctrl"], dtype=torch.float32, device=DEV), 1, out=dict(debug=impl.dbg))
+    dbg = impl.dbg.cpu().numpy().astype(np.float64)
+    f = lambda name: dbg[:, impl.lay[name][0]:impl.lay[name][0] + impl.lay[name][1]]
+    rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    worst = {}
+    for name, tol in (("xpos", 2e-6), ("xmat", 2e-6), ("cinert", 5e-6), ("cvel", 2e-5), ("qfrc_bias", 5e-5), ("qfrc_passive", 2e-6),
+                      ("qfrc_actuator", 2e-6), ("qfrc_smooth", 5e-5), ("qacc_smooth", 1e-4), ("con_dist", 2e-5), ("con_pos", 2e-6),
+                      ("con_frame", 2e-6)):
+        worst[name] = (rel(f(name), g[f"fwd_{name}"]), tol)
+    nl = len(impl.lim_dof)
+    active = g["fwd_efc_pos"][:, nl:].reshape(n, -1, 4)[:, :, 0] < 0
+    worst["con_D"] = (rel(f("con_D")[active], g["fwd_efc_D"][:, nl:].reshape(n, -1, 4)[:, :, 0][active]), 5e-5)
+    worst["con_aref"] = (rel(f("con_aref").reshape(n, -1, 4)[active], g["fwd_efc_aref"][:, nl:].reshape(n, -1, 4)[active]), 5e-5)
+    np.testing.assert_array_equal(f("con_dist") < 0, g["fwd_con_dist"] < 0)
+    np.testing.assert_array_equal(f("niter_cost")[:, 0].astype(int), g["fwd_cg8_niter"][:, 0].astype(int))
+    worst["qacc"] = (rel(f("qacc"), g["fwd_cg8_qacc"]), 2e-4)
+    worst["qpos_substep"] = (float(np.abs(ds["qpos"].cpu().numpy() - g["sub_cg8_qpos"]).max()), 2e-6)
+    worst["qvel_substep"] = (float(np.abs(ds["qvel"].cpu().numpy() - g["sub_cg8_qvel"]).max()), 1e-3)
+    print(model_name, {k: f"{v[0]:.2e}" for k, v in worst.items()})
+    bad = {k: v for k, v in worst.items() if not v[0] <= v[1]}
+    assert not bad, bad
+
+
+def test_reset_matches_oracle_init(oracle_built):
+    """`Rodent.reset`: every observation segment and qacc_warmstart against the oracle's init + get_obs (a2)."""
+    from rodent_amd import envs, jax_random
+    from tests.oracle_env import OracleRodent
+    N = 16
+    track = util.synthetic_track()
+    env = envs.get_environment("rodent", track_pos=track, num_envs=N, xml_path="rodent_optimized.xml", iterations=8, ls_iterations=8, device=DEV)
+    keys = jax_random.split(jax_random.PRNGKey(9), N)
+    hs = env.reset(keys)
+    A = OracleRodent("rodent_optimized", N, "f64", (8, 8), track)
+    B = OracleRodent("rodent_optimized", N, "f32", (8, 8), track)
+    obs = A.reset(keys); obs32 = B.reset(keys)
+    np.testing.assert_array_equal(hs.info["cur_frame"].cpu().numpy(), A.cur_frame)
+    np.testing.assert_array_equal(hs.pipeline_state.qpos.cpu().numpy(), A.state()["qpos"].astype(np.float32))   # host RNG: bit-exact
+    np.testing.assert_array_equal(hs.pipeline_state.qvel.cpu().numpy(), A.state()["qvel"].astype(np.float32))
+    got = hs.obs.cpu().numpy().astype(np.float64)
+    seg = parity.obs_segments(A.tables)
+    rows = []
+    for k, s in seg.items():
+        sc = np.maximum(np.abs(obs[:, s]).max(1), 1e-3) if k == "cinert" else 1.0
+        rows += parity.quantile_rows("obs_" + k, np.abs(got[:, s] - obs[:, s]).max(1) / sc, np.abs(obs32[:, s] - obs[:, s]).max(1) / sc, qs=(0.5, 1.0))
+    w = hs.pipeline_state.qacc_warmstart.cpu().numpy().astype(np.float64)
+    sc = np.maximum(np.abs(A.state()["qacc_warmstart"]).max(1), 1.0)
+    rows += parity.quantile_rows("qacc_warmstart", np.abs(w - A.state()["qacc_warmstart"]).max(1) / sc,
+                                 np.abs(B.state()["qacc_warmstart"] - A.state()["qacc_warmstart"]).max(1) / sc, qs=(0.5, 1.0))
+    _report("reset", dict(rows=rows))
+    floors = dict(obs_qpos=0.0, obs_qvel=0.0, obs_cinert=2e-7, obs_cvel=2e-6, obs_qfrc_actuator=2e-7, obs_track_local=2e-7, qacc_warmstart=2e-6)
+    parity.check_quantiles(rows, floors)

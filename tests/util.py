@@ -51,23 +51,8 @@ def synthetic_track(T=250):
     return np.stack([0.004 * t, np.zeros(T), np.full(T, 0.0681)], axis=1)
 
 
-def assert_f32_class(errs, gaps, floor=2e-5):
-    """Parity criterion for quantities downstream of the contact solver.
-
-    Float32 contact dynamics is chaotic: two float32 evaluations of one env step that differ only in rounding (operation
-    order, fused multiply-adds) drift apart by 1e-7 .. 1e-2 depending on how close the env is to a contact or limit
-    switching on.  The scalar float32 build of the oracle shows exactly that against its float64 build (`gaps`).  The HIP
-    result (`errs`, also against the float64 oracle) is held to the same error CLASS:
-      (a) every env:            err <= max(100 * gap + floor, 3 * max(gaps))  -- an env whose contact set flips in one
-          float32 evaluation but not in the other lands anywhere inside the batch's gap range, not near its own gap
-      (b) all but max(2, N/8) envs: err <=  10 * gap + floor
-      (c) geometric mean of (err + 1e-7) / (gap + 1e-7) <= 3: no systematic loss of accuracy against scalar float32.
-    """
-    import numpy as np
+def f32_class_stat(errs, gaps):
+    """REPORTED statistic only (round 1 used it as the gate and loosened it twice after GPU failures -- DESIGN.md section 2;
+    the gates are now the criteria of tests/parity.py): geometric mean of (err + 1e-7) / (gap + 1e-7)."""
     errs, gaps = np.asarray(errs, np.float64), np.asarray(gaps, np.float64)
-    assert np.all(np.isfinite(errs))
-    assert np.all(errs <= np.maximum(100 * gaps + floor, 3 * gaps.max())), (errs, gaps)
-    assert np.sum(errs > 10 * gaps + floor) <= max(2, len(errs) // 8), (errs, gaps)
-    gm = float(np.exp(np.mean(np.log((errs + 1e-7) / (gaps + 1e-7)))))
-    assert gm <= 3.0, (gm, errs, gaps)
-    return gm
+    return float(np.exp(np.mean(np.log((errs + 1e-7) / (gaps + 1e-7)))))
