@@ -1,4 +1,6 @@
-"""bench.py -- env-steps/sec of random-action rollouts, BASELINE.json config 2:
+"""bench.py -- env-steps/sec; default = BASELINE.json config 2 (random-action rollouts; the configuration the metric is quoted
+on); `--config 3` = the full PPO loop with the launcher's hyper-parameters, `--config 5` = rodent_pair.xml physics only.
+Config 2:
 `rodent_optimized.xml`, 2048 envs per GPU, CG 8/8, n_frames 10 (1 env-step = 10 physics substeps).
 
 A "step" is one `Rodent.step` over the whole 2048-env batch through the training wrappers
@@ -7,6 +9,10 @@ the wrapper selects; actions are fresh U(-1,1) draws made on the GPU each step. 
 resident in HBM before the timed region.  N>1: one process per GPU (torch.distributed, backend nccl
 = RCCL), env shards are independent, no data-path collective ("weak" scaling); timing is barrier +
 synchronize on both sides and the MAX over ranks.
+
+Protocol: with explicit --steps K --warmup W exactly K steps are timed once (the driver's contract).  With neither flag the
+SURVEY.md 8(d) protocol runs: 50 warm-up steps, 1000 timed steps, 5 repeats, the MEDIAN repeat is reported (covers
+episode boundaries at 150 steps).
 
 Prints ONE JSON line (rank 0) with `roofline` (HBM, algorithmic bytes/env-step from SURVEY.md 8(d) x
 envs per launch / mean kernel time from hipEvents on the launch stream) and `cpu_baseline` (the C
@@ -60,6 +66,21 @@ def pmc_traffic():
         return None
 
 
+def sq_counters():
+    """VALU-busy share and instructions per env-step of the step kernel from the latest committed SQ counter pass
+    (tools/pmc_sq.sh -> profiles/r*_sq.json); the kernel is issue / latency bound, so these -- not the HBM fraction the
+    north star asks for -- are the numbers that track kernel quality."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq.json")))
+    if not files:
+        return {}
+    try:
+        d = json.load(open(files[-1]))
+        return {k: d[k] for k in ("valu_busy_frac", "instructions_per_env_step", "valu_instructions_per_env_step", "lds_bank_conflict_frac") if k in d}
+    except Exception:
+        return {}
+
+
 def cpu_baseline(n_envs=512, steps=100):
     """The oracle (kind 'port': our C restatement; the reference JAX path cannot run here) timed on the host cores."""
     from oracle import ref
@@ -88,15 +109,30 @@ def cpu_baseline(n_envs=512, steps=100):
             "sample": f"{n_envs} envs x {steps} env-steps (10 substeps each), C oracle float32, OpenMP over envs, {dt:.1f} s"}
 
 
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--num-envs", type=int, default=NUM_ENVS, help="envs per GPU")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5), help="BASELINE.json config (2 = the headline metric's)")
+    ap.add_argument("--num-envs", type=int, default=None, help="envs per GPU (default 2048; 4096 for config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    args.protocol = "driver" if (args.steps is not None or args.warmup is not None) else "survey-8d"
+    if args.config == 3:
+        dflt = (2, 1, 1)
+    else:
+        dflt = (1000, 50, 5) if args.protocol == "survey-8d" else (100, 20, 1)
+    args.repeats = dflt[2]
+    args.steps = dflt[0] if args.steps is None else args.steps
+    args.warmup = dflt[1] if args.warmup is None else args.warmup
+    if args.num_envs is None:
+        args.num_envs = 4096 if args.config == 5 else NUM_ENVS
+    return args
 
+
+def main():
+    args = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -116,26 +152,11 @@ def main():
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
-    from rodent_amd import envs
+    from rodent_amd import envs, jax_random
     from rodent_amd.envs import wrappers
 
     N = args.num_envs
-    env = envs.get_environment("rodent", track_pos=synthetic_track(), num_envs=N, xml_path=f"{MODEL}.xml",
-                               terminate_when_unhealthy=True, solver="cg", iterations=8, ls_iterations=8, device=dev)
-    wenv = wrappers.wrap(env, episode_length=150, action_repeat=1)
-    from rodent_amd import jax_random
-    keys = jax_random.split(jax_random.fold_in(jax_random.PRNGKey(0), rank), N)
-    state = wenv.reset(keys)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-
-    def one_step(state):
-        action = torch.rand(N, env.action_size, device=dev, generator=gen) * 2 - 1
-        return wenv.step(state, action)
-
-    for _ in range(args.warmup):
-        state = one_step(state)
-    env._batch.set_timing(True)
+    model = "rodent_pair" if args.config == 5 else MODEL
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -143,41 +164,121 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        state = one_step(state)
-    fence()
-    elapsed = time.perf_counter() - t0
-    kern_ms, launches = env._batch.kernel_time()
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cpu" if share else dev, dtype=torch.float64)
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], device="cpu" if share else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert torch.isfinite(state.obs).all(), "non-finite observation in the rollout"
+        return float(t.item())
+
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    extra = {}
+    if args.config == 3:
+        # ---- the full PPO loop: a "step" is one TRAINING step = 64 unrolls x 10 env steps x N envs + 512 minibatch updates
+        from rodent_amd.training.agents.ppo import train as ppo
+        env = envs.get_environment("rodent", track_pos=synthetic_track(), num_envs=N, xml_path=f"{model}.xml",
+                                   terminate_when_unhealthy=True, solver="cg", iterations=8, ls_iterations=8, device=dev)
+        env._batch.set_timing(True)
+        times = []
+        fence()
+        ppo.train(environment=env, num_timesteps=500_000_000, num_evals=100, reward_scaling=1, episode_length=150,
+                  normalize_observations=True, action_repeat=1, unroll_length=10, num_minibatches=64, num_updates_per_batch=8,
+                  discounting=0.97, learning_rate=5e-5, entropy_cost=1e-3, num_envs=N * world, batch_size=N * world, seed=0,
+                  num_eval_envs=0, max_training_steps=args.warmup + args.steps, timing_fn=times.append)
+        fence()
+        timed = times[args.warmup:]
+        elapsed = max_over_ranks(sum(t["rollout_s"] + t["learner_s"] for t in timed))
+        env_steps_per_step = timed[0]["env_steps"]            # global (all ranks)
+        total_env_steps = env_steps_per_step * len(timed)
+        extra = {"rollout_s_per_training_step": sum(t["rollout_s"] for t in timed) / len(timed),
+                 "learner_s_per_training_step": sum(t["learner_s"] for t in timed) / len(timed),
+                 "env_steps_per_training_step": env_steps_per_step}
+        workload = ("full PPO loop, launcher hyper-parameters (unroll 10, 64 minibatches x 8 epochs, lr 5e-5), rodent_optimized.xml, "
+                    "CG 8/8, n_frames 10; step = one training step")
+        batch = env._batch
+        repeats_ms = [elapsed / len(timed) * 1e3]
+    else:
+        if args.config == 2:
+            env = envs.get_environment("rodent", track_pos=synthetic_track(), num_envs=N, xml_path=f"{model}.xml",
+                                       terminate_when_unhealthy=True, solver="cg", iterations=8, ls_iterations=8, device=dev)
+            wenv = wrappers.wrap(env, episode_length=150, action_repeat=1)
+            keys = jax_random.split(jax_random.fold_in(jax_random.PRNGKey(0), rank), N)
+            state = wenv.reset(keys)
+            batch, nu = env._batch, env.action_size
+
+            def one_step(state):
+                action = torch.rand(N, nu, device=dev, generator=gen) * 2 - 1
+                return wenv.step(state, action)
+            workload = f"{model}.xml random-action rollout, Rodent.step through Episode(150)+AutoReset wrappers, CG 8/8, n_frames 10"
+        else:
+            # ---- config 5: rodent_pair.xml (two replicated rodents, nv 146, 114 contacts), physics only (pipeline_step)
+            from rodent_amd import assets, hip, mjcf
+            path = assets.asset_path(model)
+            m = mjcf.load_blob(path)
+            batch = hip.Batch(hip.Model(path, 8, 8), N, dev)
+            d = batch.dims
+            nu = d.nu
+            q = torch.tensor(np.tile(m["qpos0"], (N, 1)), dtype=torch.float32, device=dev)
+            q += (torch.rand(N, d.nq, device=dev, generator=gen) * 2 - 1) * 0.01
+            state = dict(qpos=q, qvel=torch.zeros(N, d.nv, device=dev), act=torch.zeros(N, d.na, device=dev),
+                         qacc_warmstart=torch.zeros(N, d.nv, device=dev))
+            batch.pipeline_init(state)
+            first = {k: v.clone() for k, v in state.items()}
+
+            def one_step(state):
+                ctrl = torch.rand(N, nu, device=dev, generator=gen) * 2 - 1
+                out = {k: torch.empty_like(v) for k, v in state.items()}
+                batch.pipeline_step_to(state, out, ctrl, 10)
+                bad = (out["qpos"][:, 2] < 0.03) | (out["qpos"][:, 2] > 0.5) | ~torch.isfinite(out["qpos"]).all(1)   # keep the population in contact
+                for k in out:
+                    out[k] = torch.where(bad[:, None], first[k], out[k])
+                return out
+            workload = f"{model}.xml physics only (pipeline_step, n_frames 10), random actions, CG 8/8, restart of fallen envs"
+        for _ in range(args.warmup):
+            state = one_step(state)
+        batch.set_timing(True)
+        repeats_ms = []
+        for rep in range(args.repeats):
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                state = one_step(state)
+            fence()
+            repeats_ms.append(max_over_ranks(time.perf_counter() - t0) / args.steps * 1e3)
+        obs = state.obs if args.config == 2 else state["qpos"]
+        assert torch.isfinite(obs).all(), "non-finite state in the rollout"
+        total_env_steps = N * world * args.steps
+        elapsed = float(np.median(repeats_ms)) * args.steps * 1e-3
+    kern_ms, launches = batch.kernel_time()
 
     if rank == 0:
-        total_env_steps = N * world * args.steps
         value = total_env_steps / elapsed
-        d = env.sys.model.dims
+        d = batch.dims
         S = d.nq + d.nv + d.na + d.nv
-        bytes_per_env_step = 4 * (2 * S + d.nu + d.obs_dim + 2)          # 7180 B for rodent_optimized
+        # full env step 4(2S + nu + obs + 2) = 7180 B (rodent_optimized); physics only 4(2S + nu) (config 5: 3880 B)
+        bytes_per_env_step = 4 * (2 * S + d.nu + (d.obs_dim + 2 if args.config != 5 else 0))
         avg_kernel_s = (kern_ms / max(launches, 1)) * 1e-3
         achieved = bytes_per_env_step * N / avg_kernel_s / 1e9
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic() if args.config == 2 else None,
+                "kernel": "rr_step_kernel", "avg_kernel_ms": avg_kernel_s * 1e3, "launches": launches,
+                "algorithmic_bytes_per_env_step": bytes_per_env_step,
+                "limiter": "VALU issue + dependent LDS/L2 latency, not HBM (SURVEY.md 8(d)); see valu_busy_frac"}
+        if args.config == 2:
+            roof.update(sq_counters())
         out = {
             "metric": "env-steps/sec (whole node), rodent 2048 envs/GPU", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{MODEL}.xml random-action rollout, Rodent.step through Episode(150)+AutoReset wrappers, "
-                                   f"CG 8/8, n_frames 10", "envs_per_gpu": N, "global_envs": N * world,
-                       "parallelism": f"env-shards x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
-                         "kernel": "rr_step_kernel", "avg_kernel_ms": avg_kernel_s * 1e3, "launches": launches,
-                         "algorithmic_bytes_per_env_step": bytes_per_env_step},
+            "config": {"workload": workload, "baseline_config": args.config, "envs_per_gpu": N, "global_envs": N * world,
+                       "parallelism": f"env-shards x{world}" + (", no data-path collective" if args.config != 3 else
+                                                                ", gradient + normaliser all-reduce (RCCL)"),
+                       "protocol": args.protocol, "repeats": args.repeats, "ms_per_step_repeats": repeats_ms, **extra},
+            "roofline": roof,
             "cpu_baseline": None,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == 2:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if dist is not None:

@@ -61,6 +61,7 @@ static void layout(rr_model* m) {
   k.g_con_dist = dbg("con_dist", d.ncon); k.g_con_pos = dbg("con_pos", 3 * d.ncon); k.g_con_frame = dbg("con_frame", 9 * d.ncon);
   k.g_con_D = dbg("con_D", d.ncon); k.g_con_aref = dbg("con_aref", 4 * d.ncon); k.g_lim = dbg("limit_pos_D_aref", 3 * d.nv);
   k.g_qacc = dbg("qacc", d.nv); k.g_qfrc_constraint = dbg("qfrc_constraint", d.nv); k.g_misc = dbg("niter_cost", 2);
+  k.g_kaok = dbg("kernarg_ok", 1);
   k.dbg_floats = g;
   for (auto& s : m->dbg_names) m->dbg_cnames.push_back(s.c_str());
   m->dims.lds_bytes = o * (int)sizeof(float);
@@ -153,6 +154,21 @@ extern "C" int rr_model_set_solver(rr_model* m, int32_t it, int32_t ls) {
   return RR_OK;
 }
 extern "C" void rr_model_destroy(rr_model* m) { delete m; }
+extern "C" int rr_model_table(const rr_model* m, const char* name, const void** host_ptr, size_t* count, int32_t* dtype) {
+  if (!m || !name || !host_ptr) return fail(RR_EINVAL, "rr_model_table: null argument");
+  const Entry* e = m->find(name);
+  if (!e) return fail(RR_EINVAL, std::string("rr_model_table: the model has no table '") + name + "'");
+  *host_ptr = e->data;
+  if (count) *count = e->count;
+  if (dtype) *dtype = e->dtype;
+  return RR_OK;
+}
+extern "C" int rr_kernarg_layout(int32_t* io_offset, int32_t* io_size, int32_t* total_size) {
+  if (io_offset) *io_offset = (int32_t)offsetof(RRKArgs, io);
+  if (io_size) *io_size = (int32_t)sizeof(RRIO);
+  if (total_size) *total_size = (int32_t)sizeof(RRKArgs);
+  return RR_OK;
+}
 
 // ------------------------------------------------------------------------------------------ batch
 struct rr_batch {
@@ -163,10 +179,10 @@ struct rr_batch {
   RRTables T;
   std::vector<void*> dev_allocs;
   bool timing = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<hipEvent_t> ev0, ev1;     // ring of event pairs: launches are timed without a host sync per launch
+  int npending = 0;
   double total_ms = 0;
   int64_t launches = 0;
-  bool pending = false;
   unsigned long long* prof = nullptr;   // diagnostic phase-cycle buffer (rr_batch_set_profile)
 };
 
@@ -249,20 +265,21 @@ extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t devi
 extern "C" void rr_batch_destroy(rr_batch* b) {
   if (!b) return;
   for (void* p : b->dev_allocs) (void)hipFree(p);
-  if (b->ev0) (void)hipEventDestroy(b->ev0);
-  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  for (hipEvent_t e : b->ev0) (void)hipEventDestroy(e);
+  for (hipEvent_t e : b->ev1) (void)hipEventDestroy(e);
   delete b;
 }
 
+#define RR_TIMING_RING 256
 static int collect_timing(rr_batch* b) {
-  if (b->pending) {
-    HIPCHK(hipEventSynchronize(b->ev1));
+  if (b->npending > 0) HIPCHK(hipEventSynchronize(b->ev1[b->npending - 1]));    // same stream: the earlier ones are done too
+  for (int i = 0; i < b->npending; ++i) {
     float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+    HIPCHK(hipEventElapsedTime(&ms, b->ev0[i], b->ev1[i]));
     b->total_ms += ms;
     b->launches += 1;
-    b->pending = false;
   }
+  b->npending = 0;
   return RR_OK;
 }
 
@@ -279,6 +296,7 @@ static int launch(rr_batch* b, const rr_state* st, const float* ctrl, int n_fram
   if (out) {
     io.o_cinert = out->cinert; io.o_cvel = out->cvel; io.o_qfrc_actuator = out->qfrc_actuator; io.o_xpos = out->xpos;
     io.o_xmat = out->xmat; io.o_com = out->subtree_com; io.dbg = out->debug;
+    io.o_cdist = out->contact_dist; io.o_cpos = out->contact_pos; io.o_cframe = out->contact_frame;
   }
   if (env) {
     if (!env->obs || !env->track_pos || !env->cur_frame || env->track_len <= 0) return fail(RR_EINVAL, "launch: env io needs obs, track_pos, cur_frame");
@@ -291,21 +309,20 @@ static int launch(rr_batch* b, const rr_state* st, const float* ctrl, int n_fram
   }
   io.mode = mode;
   HIPCHK(hipSetDevice(b->device));
-  kern_t kern = pick_kernel(b->m, b->prof != nullptr, io.dbg != nullptr);
+  kern_t kern = pick_kernel(b->m, b->prof != nullptr, io.dbg != nullptr || io.o_cdist || io.o_cpos || io.o_cframe);
   if (!kern) return fail(RR_EUNSUPPORTED, "launch: no diagnostic kernel instance for this model");
   io.prof = b->prof;
   RRDims kd = b->kd;
   kd.iterations = b->m->kd.iterations; kd.ls_iterations = b->m->kd.ls_iterations;
   if (b->timing) {
-    int rc = collect_timing(b);
-    if (rc) return rc;
-    HIPCHK(hipEventRecord(b->ev0, b->stream));
+    if (b->npending == RR_TIMING_RING) { int rc = collect_timing(b); if (rc) return rc; }
+    HIPCHK(hipEventRecord(b->ev0[b->npending], b->stream));
   }
   hipLaunchKernelGGL(kern, dim3(b->N), dim3(RR_LANES), (size_t)b->m->dims.lds_bytes, b->stream, kd, b->T, io, b->N, n_frames);
   HIPCHK(hipGetLastError());
   if (b->timing) {
-    HIPCHK(hipEventRecord(b->ev1, b->stream));
-    b->pending = true;
+    HIPCHK(hipEventRecord(b->ev1[b->npending], b->stream));
+    b->npending += 1;
   }
   return RR_OK;
 }
@@ -437,9 +454,15 @@ extern "C" int rr_batch_set_profile(rr_batch* b, uint64_t* dev_cycles) {
 extern "C" int rr_batch_set_timing(rr_batch* b, int32_t enable) {
   if (!b) return fail(RR_EINVAL, "rr_batch_set_timing: null batch");
   HIPCHK(hipSetDevice(b->device));
-  if (enable && !b->ev0) { HIPCHK(hipEventCreate(&b->ev0)); HIPCHK(hipEventCreate(&b->ev1)); }
+  if (enable && b->ev0.empty()) {
+    for (int i = 0; i < RR_TIMING_RING; ++i) {
+      hipEvent_t a, c;
+      HIPCHK(hipEventCreate(&a)); b->ev0.push_back(a);
+      HIPCHK(hipEventCreate(&c)); b->ev1.push_back(c);
+    }
+  }
   b->timing = enable != 0;
-  b->total_ms = 0; b->launches = 0; b->pending = false;
+  b->total_ms = 0; b->launches = 0; b->npending = 0;
   return RR_OK;
 }
 extern "C" int rr_batch_kernel_time(rr_batch* b, double* total_ms, int64_t* launches) {

@@ -36,7 +36,7 @@ struct RRDims {
   // debug dump offsets (floats)
   int g_xpos, g_xquat, g_xmat, g_com, g_cinert, g_crb, g_cdof, g_cvel, g_cfrc, g_qM, g_qLD, g_dinv, g_bias, g_passive,
       g_actuator, g_smooth, g_qacc_smooth, g_con_dist, g_con_pos, g_con_frame, g_con_D, g_con_aref, g_lim, g_qacc,
-      g_qfrc_constraint, g_misc, dbg_floats;
+      g_qfrc_constraint, g_misc, g_kaok, dbg_floats;
 };
 
 // LDS layout of one environment (float offsets).  One constexpr function serves the host (rr_api.hip layout) and the
@@ -109,6 +109,7 @@ struct RRIO {
   const int* cur_frame_in;
   const float* ctrl;
   float *o_cinert, *o_cvel, *o_qfrc_actuator, *o_xpos, *o_xmat, *o_com, *dbg;
+  float *o_cdist, *o_cpos, *o_cframe;                      // contact geometry of the last forward pass (optional)
   // env epilogue
   const float* track_pos;
   int track_len;
@@ -1042,7 +1043,7 @@ struct Wave {
   // ---------------------------------------------------------------- A-4 collision: contact geometry -> registers
   // Runs right after com_pos while xpos / xquat are still live; the Jacobian is never materialised: a contact keeps
   // its offset from the tree COM and its frame, and J x / J' f are evaluated on the fly from cdof (J-free products).
-  __device__ __forceinline__ void contact_geometry(float* dbg) {
+  __device__ __forceinline__ void contact_geometry(float* dbg, float* o_dist = nullptr, float* o_pos = nullptr, float* o_frame = nullptr) {
 #pragma unroll
     for (int cs = 0; cs < NCS; ++cs) {
       const int c = lane + RR_LANES * cs;
@@ -1101,6 +1102,9 @@ struct Wave {
           st3(dbg + D.g_con_pos + 3 * c, pos);
           st3(dbg + D.g_con_frame + 9 * c, n); st3(dbg + D.g_con_frame + 9 * c + 3, fb); st3(dbg + D.g_con_frame + 9 * c + 6, fc);
         }
+        if (o_dist) o_dist[c] = dist;
+        if (o_pos) st3(o_pos + 3 * c, pos);
+        if (o_frame) { st3(o_frame + 9 * c, n); st3(o_frame + 9 * c + 3, fb); st3(o_frame + 9 * c + 6, fc); }
         if (dist < 0) {
           con_act[cs] = true;
           float k, bcoef, imp;
@@ -1605,7 +1609,17 @@ struct Wave {
 // The kernel's explicit arguments as they lie in the kernarg segment.  The ~20 pointers of RRIO are needed only before the
 // first and after the last substep; read through the (opaque) kernarg pointer where they are used, they do not occupy
 // scalar registers -- or their spill lanes -- during the substeps.
+// ASSUMPTION (AMDGPU kernel ABI): explicit by-value arguments are laid out in the kernarg segment in declaration order,
+// each at its natural alignment -- i.e. like the members of this struct.  Guards: the static_asserts below pin the struct's
+// own layout rules; tests/test_abi_and_oracle.py compares rr_kernarg_layout() with the argument offsets the device compiler
+// recorded in the code object (tools/kernel_meta.py); and the debug-dump instance compares the block it re-reads with the
+// real `io_kernarg` parameter on every launch (dump field `kernarg_ok`).
 struct RRKArgs { RRDims D; RRTables T; RRIO io; int num_envs, n_frames; };
+constexpr size_t rr_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static_assert(alignof(RRDims) == 4 && alignof(RRTables) == 8 && alignof(RRIO) == 8, "argument alignments the kernarg layout relies on");
+static_assert(offsetof(RRKArgs, T) == rr_align_up(sizeof(RRDims), alignof(RRTables)), "RRTables follows RRDims at its natural alignment");
+static_assert(offsetof(RRKArgs, io) == rr_align_up(offsetof(RRKArgs, T) + sizeof(RRTables), alignof(RRIO)), "RRIO follows RRTables at its natural alignment");
+static_assert(offsetof(RRKArgs, num_envs) == offsetof(RRKArgs, io) + sizeof(RRIO) && sizeof(RRIO) % 8 == 0, "scalars follow RRIO without padding");
 static __device__ __forceinline__ RRIO load_io() {
 #if defined(__HIP_DEVICE_COMPILE__)
   const char __attribute__((address_space(4)))* p = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1628,9 +1642,16 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
   Wave<NBS, NVS, NCS, DT> w(D, T, lds);
   const int lane = threadIdx.x;
   RRIO io = load_io();
+  if (DBG) {   // the re-read block must be the real parameter, word for word; on a mismatch say so in the dump and touch nothing else
+    const RRIO ref_io = io_kernarg;
+    bool same = true;
+    for (unsigned i = 0; i < sizeof(RRIO) / sizeof(int); ++i) same &= ((const int*)&io)[i] == ((const int*)&ref_io)[i];
+    if (ref_io.dbg && lane == 0) ref_io.dbg[(size_t)env * D.dbg_floats + D.g_kaok] = same ? 1.0f : 0.0f;
+    if (!same) return;
+  }
   const int mode = io.mode;
   // the debug dump (parity tests) is a separate instance: its paths keep dozens of values alive across the solver
-  float* dbg = (DBG && io.dbg) ? io.dbg + (size_t)env * D.dbg_floats : nullptr;
+  float* dbg = (DBG && io.dbg) ? io.dbg + (size_t)env * D.dbg_floats : nullptr;     // DBG instance without a dump buffer: contact outputs only
 
   // ---- load state
   for (int i = lane; i < D.nq; i += RR_LANES) w.s_qpos[i] = io.qpos_in[(size_t)env * D.nq + i];
@@ -1721,7 +1742,15 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
         if (lane == 0) { for (int k = 0; k < 3; ++k) { dg[D.g_com + k] = w.com0[k]; dg[D.g_com + 3 + k] = w.com1[k]; } }
       }
     }
-    w.contact_geometry(dg);
+    {   // contact geometry outputs (on request only) are served by the debug-dump instance: the production instances carry no code for them
+      float *od = nullptr, *op = nullptr, *of = nullptr;
+      if (DBG && last) {
+        od = io.o_cdist ? io.o_cdist + (size_t)env * D.ncon : nullptr;
+        op = io.o_cpos ? io.o_cpos + (size_t)env * 3 * D.ncon : nullptr;
+        of = io.o_cframe ? io.o_cframe + (size_t)env * 9 * D.ncon : nullptr;
+      }
+      w.contact_geometry(dg, od, op, of);
+    }
     w.velocity_sweep();
     w.template stamp<PROF>(2);
     if (last) {   // cinert / cvel of the last forward pass go out now: cinert's cells become the composite inertia next

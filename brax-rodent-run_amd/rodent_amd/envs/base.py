@@ -20,11 +20,19 @@ class PipelineState:
     qvel: torch.Tensor            # [N, nv]
     act: torch.Tensor             # [N, na]
     qacc_warmstart: torch.Tensor  # [N, nv]
-    cinert: torch.Tensor          # [N, nbody, 10]
-    cvel: torch.Tensor            # [N, nbody, 6]
-    qfrc_actuator: torch.Tensor   # [N, nv]
-    xpos: torch.Tensor            # [N, nbody, 3]
-    xmat: torch.Tensor            # [N, nbody, 9]
+    # Derived quantities of the last forward pass.  `Rodent.step` leaves them None unless the env was built with
+    # `pipeline_outputs=True`: the observation already carries cinert / cvel / qfrc_actuator [REF Rodent_Env_Brax.py:151-155]
+    # and writing them a second time was 7.7 KB per env-step of HBM traffic (+ the AutoReset select over them).
+    cinert: Optional[torch.Tensor] = None          # [N, nbody, 10]
+    cvel: Optional[torch.Tensor] = None            # [N, nbody, 6]
+    qfrc_actuator: Optional[torch.Tensor] = None   # [N, nv]
+    xpos: Optional[torch.Tensor] = None            # [N, nbody, 3]
+    xmat: Optional[torch.Tensor] = None            # [N, nbody, 9]
+    # brax `State.contact` (mjx.Data.contact) geometry [NB mjcf.ipynb:917-921]; filled with `contact_outputs=True`;
+    # the static integer fields are `sys.contact_geom1 / contact_geom2 / contact_link_idx`
+    contact_dist: Optional[torch.Tensor] = None    # [N, ncon]
+    contact_pos: Optional[torch.Tensor] = None     # [N, ncon, 3]
+    contact_frame: Optional[torch.Tensor] = None   # [N, ncon, 3, 3]
 
     @property
     def q(self):
@@ -38,7 +46,7 @@ class PipelineState:
         return dataclasses.replace(self, **kw)
 
     def tree(self):
-        return {f.name: getattr(self, f.name) for f in dataclasses.fields(self)}
+        return {f.name: getattr(self, f.name) for f in dataclasses.fields(self) if getattr(self, f.name) is not None}
 
 
 @dataclasses.dataclass
@@ -68,18 +76,28 @@ class System:
         self.obs_dim = d.obs_dim
         self.dt = float(d.timestep)
         self.qpos0 = self.tables["qpos0"]
+        self.ncon = d.ncon
+        # integer ids as the LOADED model holds them (C ABI rr_model_table): Contact.geom1 / geom2 and brax's link_idx
+        # (= geom_bodyid[g] - 1) [NB mjcf.ipynb:917-921]
+        self.contact_geom1 = self.model.table("con_geom1")
+        self.contact_geom2 = self.model.table("con_geom2")
+        self.geom_bodyid = self.model.table("geom_bodyid")
+        self.contact_link_idx = (self.geom_bodyid[self.contact_geom1] - 1, self.geom_bodyid[self.contact_geom2] - 1)
 
 
 class PipelineEnv:
     """API for driving the HIP physics backend (`brax.envs.base.PipelineEnv` with backend='mjx'
     replaced by the fused HIP kernel): `pipeline_init` / `pipeline_step` [REF Rodent_Env_Brax.py:87,101]."""
 
-    def __init__(self, sys: System, num_envs: int, n_frames: int = 1, backend: str = "hip", device=None, debug=False):
+    def __init__(self, sys: System, num_envs: int, n_frames: int = 1, backend: str = "hip", device=None, debug=False,
+                 pipeline_outputs: bool = False, contact_outputs: bool = False):
         if backend not in ("hip", "mjx"):
             raise ValueError(f"backend {backend!r} not available: this build provides the HIP backend only")
         self.sys = sys
         self._n_frames = n_frames
         self._debug = debug
+        self._pipeline_outputs = pipeline_outputs
+        self._contact_outputs = contact_outputs
         self.num_envs = int(num_envs)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._batch = hip.Batch(sys.model, self.num_envs, self.device)
@@ -101,11 +119,19 @@ class PipelineEnv:
     def backend(self) -> str:
         return "hip"
 
-    def _alloc_outputs(self):
+    def _alloc_outputs(self, full: bool = True):
+        """Buffers for the optional rr_outputs; `full=False` honours the env's pipeline_outputs / contact_outputs switches
+        (the rollout path: nothing unless asked for)."""
         N, s, dev = self.num_envs, self.sys, self.device
-        return dict(cinert=torch.empty(N, s.nbody, 10, device=dev), cvel=torch.empty(N, s.nbody, 6, device=dev),
-                    qfrc_actuator=torch.empty(N, s.nv, device=dev), xpos=torch.empty(N, s.nbody, 3, device=dev),
-                    xmat=torch.empty(N, s.nbody, 9, device=dev))
+        out = {}
+        if full or self._pipeline_outputs:
+            out.update(cinert=torch.empty(N, s.nbody, 10, device=dev), cvel=torch.empty(N, s.nbody, 6, device=dev),
+                       qfrc_actuator=torch.empty(N, s.nv, device=dev), xpos=torch.empty(N, s.nbody, 3, device=dev),
+                       xmat=torch.empty(N, s.nbody, 9, device=dev))
+        if self._contact_outputs:
+            out.update(contact_dist=torch.empty(N, s.ncon, device=dev), contact_pos=torch.empty(N, s.ncon, 3, device=dev),
+                       contact_frame=torch.empty(N, s.ncon, 3, 3, device=dev))
+        return out
 
     def pipeline_init(self, q: torch.Tensor, qd: torch.Tensor) -> PipelineState:
         N, s, dev = self.num_envs, self.sys, self.device

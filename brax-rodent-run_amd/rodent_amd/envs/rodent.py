@@ -60,7 +60,8 @@ class Rodent(PipelineEnv):
                           healthy_reward=healthy_reward, terminate_when_unhealthy=terminate_when_unhealthy,
                           healthy_z_range=healthy_z_range, reset_noise_scale=reset_noise_scale, solver=solver,
                           iterations=iterations, ls_iterations=ls_iterations, vision=vision, xml_path=xml_path,
-                          n_frames=kwargs["n_frames"])
+                          n_frames=kwargs["n_frames"], pipeline_outputs=kwargs.get("pipeline_outputs", False),
+                          contact_outputs=kwargs.get("contact_outputs", False))
 
     def with_num_envs(self, num_envs: int, device=None):
         """A sibling env with another batch size (ppo.train builds its per-rank and eval envs this way)."""
@@ -89,7 +90,7 @@ class Rodent(PipelineEnv):
 
         st = dict(qpos=torch.from_numpy(qpos).to(dev), qvel=torch.from_numpy(qvel).to(dev),
                   act=torch.zeros(N, s.na, device=dev), qacc_warmstart=torch.zeros(N, s.nv, device=dev))
-        out = self._alloc_outputs()
+        out = self._alloc_outputs(full=False)
         cur_frame = torch.from_numpy(start_frame.astype(np.int32)).to(dev)
         obs = torch.empty(N, s.obs_dim, device=dev)
         self._batch.env_reset(st, self._env_io(cur_frame, obs), out)
@@ -103,7 +104,7 @@ class Rodent(PipelineEnv):
         ps = state.pipeline_state
         st_in = dict(qpos=ps.qpos, qvel=ps.qvel, act=ps.act, qacc_warmstart=ps.qacc_warmstart)
         st = {k: torch.empty_like(v) for k, v in st_in.items()}      # the previous state is left untouched (no copies)
-        out = self._alloc_outputs()
+        out = self._alloc_outputs(full=False)
         cur_frame = torch.empty_like(state.info["cur_frame"])
         obs = torch.empty(N, s.obs_dim, device=dev)
         reward, done = torch.empty(N, device=dev), torch.empty(N, device=dev)

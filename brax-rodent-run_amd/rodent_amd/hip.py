@@ -27,7 +27,8 @@ class RRState(C.Structure):
 
 
 class RROutputs(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("cinert", "cvel", "qfrc_actuator", "xpos", "xmat", "subtree_com", "debug")]
+    _fields_ = [(n, C.c_void_p) for n in ("cinert", "cvel", "qfrc_actuator", "xpos", "xmat", "subtree_com", "debug",
+                                                "contact_dist", "contact_pos", "contact_frame")]
 
 
 class RREnvIO(C.Structure):
@@ -37,7 +38,7 @@ class RREnvIO(C.Structure):
                 ("terminate_when_unhealthy", C.c_int32)]
 
 
-EXPORTS = ["rr_model_load", "rr_model_dims", "rr_model_set_solver", "rr_model_destroy", "rr_batch_create",
+EXPORTS = ["rr_model_load", "rr_model_dims", "rr_model_set_solver", "rr_model_destroy", "rr_model_table", "rr_kernarg_layout", "rr_batch_create",
            "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset", "rr_pipeline_step_to", "rr_env_step_to",
            "rr_compute_gae", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
 
@@ -57,6 +58,8 @@ def lib():
         L.rr_model_set_solver.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         L.rr_model_destroy.argtypes = [C.c_void_p]
         L.rr_model_destroy.restype = None
+        L.rr_model_table.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
+        L.rr_kernarg_layout.argtypes = [C.POINTER(C.c_int32)] * 3
         L.rr_batch_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
         L.rr_batch_destroy.argtypes = [C.c_void_p]
         L.rr_batch_destroy.restype = None
@@ -105,6 +108,14 @@ class Model:
         if iterations is not None:
             d = self.dims
             _check(lib().rr_model_set_solver(self.h, iterations, ls_iterations if ls_iterations is not None else d.ls_iterations))
+
+    def table(self, name: str):
+        """A static table of the LOADED model by its MuJoCo field name (C ABI `rr_model_table`) as a numpy copy."""
+        import numpy as np
+        ptr, cnt, dt = C.c_void_p(), C.c_size_t(), C.c_int32()
+        _check(lib().rr_model_table(self.h, name.encode(), C.byref(ptr), C.byref(cnt), C.byref(dt)))
+        ctype = C.c_float if dt.value == 0 else C.c_int32
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(cnt.value,)).copy()
 
     @property
     def dims(self) -> RRDims:
@@ -158,7 +169,10 @@ class Batch:
             return None
         d, N = self.dims, self.N
         sizes = dict(cinert=10 * d.nbody, cvel=6 * d.nbody, qfrc_actuator=d.nv, xpos=3 * d.nbody, xmat=9 * d.nbody,
-                     subtree_com=3, debug=d.dbg_floats)
+                     subtree_com=3, debug=d.dbg_floats, contact_dist=d.ncon, contact_pos=3 * d.ncon, contact_frame=9 * d.ncon)
+        unknown = set(out) - set(sizes)
+        if unknown:
+            raise ValueError(f"unknown rr_outputs field(s): {sorted(unknown)}")
         o = RROutputs()
         for k, w in sizes.items():
             setattr(o, k, _ptr(out.get(k), numel=N * w) if out.get(k) is not None else None)

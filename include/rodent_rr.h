@@ -60,6 +60,11 @@ typedef struct rr_outputs {
   float* xmat;          /* [N][nbody*9]  */
   float* subtree_com;   /* [N][3]  (root 0) */
   float* debug;         /* [N][dims.dbg_floats], see rr_debug_layout; NULL in production */
+  /* contact geometry of the last forward pass (mjx.Data.contact.{dist,pos,frame}; brax State.contact
+   * [NB mjcf.ipynb:917-921]); the integer fields geom1 / geom2 / link_idx are static: rr_model_table */
+  float* contact_dist;  /* [N][ncon]   */
+  float* contact_pos;   /* [N][ncon*3] */
+  float* contact_frame; /* [N][ncon*9]: rows normal, tangent 1, tangent 2 */
 } rr_outputs;
 
 /* reference-env epilogue fused into the step kernel [REF Rodent_Env_Brax.py:98-136]; all NULL = physics only */
@@ -83,6 +88,12 @@ int rr_model_dims(const rr_model* m, rr_dims* out);
 /* opt.iterations / opt.ls_iterations override [REF Rodent_Env_Brax.py:46-47] (before rr_batch_create) */
 int rr_model_set_solver(rr_model* m, int32_t iterations, int32_t ls_iterations);
 void rr_model_destroy(rr_model* m);
+/* Static model tables as the LOADED model holds them (the integer ids the reference exposes through `sys` / `Contact`:
+ * "con_geom1", "con_geom2" = Contact.geom1 / geom2 [NB mjcf.ipynb:917-921], "con_body1", "con_body2" (+1 of brax's
+ * contact.link_idx), "geom_bodyid", "dof_bodyid", "dof_parentid", "body_parentid", "jnt_qposadr", "jnt_dofadr",
+ * "actuator_dofadr", ... -- any entry of the blob by its MuJoCo field name).  Returns a borrowed HOST pointer valid for
+ * the model's lifetime; *dtype: 0 = float32, 1 = int32; *count = number of elements.  RR_EINVAL for an unknown name. */
+int rr_model_table(const rr_model* m, const char* name, const void** host_ptr, size_t* count, int32_t* dtype);
 
 /* -- batch ------------------------------------------------------------------------------------- */
 /* Upload the model tables to `hip_device` and bind `hip_stream` (a hipStream_t, may be NULL = default). */
@@ -142,6 +153,11 @@ int rr_batch_kernel_time(rr_batch* b, double* total_ms, int64_t* launches);
 /* Diagnostic only (never in a timed run): route launches to the s_memtime-instrumented build of the kernel, which
  * writes per-phase cycle sums of each env into dev_cycles [N][16] (uint64, device).  NULL switches back. */
 int rr_batch_set_profile(rr_batch* b, uint64_t* dev_cycles);
+
+/* Build-consistency probe (tests): byte offset and size of the I/O block inside the step kernel's argument segment as the
+ * HOST code assumes them (the kernel re-reads that block through the kernarg segment pointer; tools/kernel_meta.py reads the
+ * offsets the device compiler actually assigned from the code object's metadata and tests/test_abi_and_oracle.py compares). */
+int rr_kernarg_layout(int32_t* io_offset, int32_t* io_size, int32_t* total_size);
 
 const char* rr_last_error(void);
 

@@ -23,6 +23,46 @@ def test_library_exports_every_declared_symbol():
         assert getattr(lib, sym) is not None
 
 
+def test_kernarg_layout_matches_the_code_object():
+    """The step kernel re-reads its I/O block through the kernarg segment pointer at offsetof(RRKArgs, io): that offset (and
+    the block's size) must be what the DEVICE compiler assigned to the third explicit argument of every rr_step_kernel
+    instance (code-object metadata, tools/kernel_meta.py).  Round 1 recorded a nil-address GPU fault while this mechanism
+    was being introduced (gpurun_out/dbg_abort.log); this is the build-time guard."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_meta
+    off, size, total = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    hip.lib().rr_kernarg_layout(ctypes.byref(off), ctypes.byref(size), ctypes.byref(total))
+    ks = [k for k in kernel_meta.kernels(hip.LIB_PATH) if "rr_step_kernel" in k["name"]]
+    assert len(ks) >= 8
+    for k in ks:
+        explicit = [a for a in k["args"] if a[2] == "by_value"]
+        assert len(explicit) == 5, k["name"]
+        assert explicit[2][:2] == (off.value, size.value), (k["name"], explicit, off.value, size.value)
+        assert explicit[4][0] + explicit[4][1] == total.value
+        assert k["lds"] == 0                      # the level schedules address LDS from byte 0: no static LDS
+
+
+def test_model_tables_through_the_abi():
+    """The integer ids the north star calls bit-exact, read back from the LOADED model through rr_model_table:
+    Contact.geom1 / geom2 of rodent_optimized = plane-capsule pairs ascending (2 points each), then the plane-ellipsoid
+    pairs [SURVEY.md Appendix B; ordering rule confirmed by NB mjcf.ipynb:917-921], and brax's link_idx = geom_bodyid - 1."""
+    m = hip.Model(assets.asset_path("rodent_optimized"))
+    caps = [11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 31, 42, 86, 87, 88, 90, 91, 92, 94, 95, 96, 98, 99, 100]
+    want = [g for c in caps for g in (c, c)] + [1, 62, 75, 89, 97]
+    assert m.table("con_geom2").tolist() == want
+    assert m.table("con_geom1").tolist() == [0] * 59
+    gb = m.table("geom_bodyid")
+    assert gb.dtype == np.int32 and len(gb) == 101
+    assert (gb[m.table("con_geom2")] == m.table("con_body2")).all()
+    blob = mjcf.load_blob(assets.asset_path("rodent_optimized"))
+    for name in ("dof_bodyid", "dof_parentid", "body_parentid", "jnt_qposadr", "jnt_dofadr", "actuator_dofadr", "con_kind"):
+        assert m.table(name).tolist() == blob[name].ravel().tolist(), name
+    assert m.table("body_mass").dtype == np.float32
+    with pytest.raises(RuntimeError, match="no table"):
+        m.table("no_such_table")
+
+
 def test_model_load_dims_and_errors_without_gpu():
     m = hip.Model(assets.asset_path("rodent_optimized"), iterations=8, ls_iterations=8)
     d = m.dims

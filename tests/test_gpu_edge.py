@@ -79,7 +79,7 @@ def test_cur_frame_saturates_like_a_clamped_gather(oracle_built):
     from rodent_amd import envs
     track = util.synthetic_track(T=20)
     env = envs.get_environment("rodent", track_pos=track, num_envs=3, xml_path="rodent_optimized.xml", iterations=8,
-                               ls_iterations=8, device=DEV)
+                               ls_iterations=8, device=DEV, pipeline_outputs=True)
     s = env.reset(1)
     s.info["cur_frame"] = torch.tensor([18, 19, 400], dtype=torch.int32, device=DEV)
     n = env.step(s, torch.zeros(3, env.action_size, device=DEV))
@@ -123,3 +123,67 @@ def test_argument_errors_are_reported_not_crashed():
     bad = dict(st); bad["qpos"] = st["qpos"].double()
     with pytest.raises(ValueError):
         b.pipeline_init(bad)
+
+
+def test_optional_outputs_all_null_and_all_set(oracle_built):
+    """The debug-dump instance with every optional rr_outputs pointer NULL except the dump, and with all of them set: the
+    kernel's re-read of its I/O block through the kernarg segment must equal the real parameter (dump field `kernarg_ok`),
+    the states must be bit-identical, and the contact geometry outputs / pose outputs must equal the dump's fields."""
+    from rodent_amd import assets
+    ref = oracle_built
+    N = 8
+    b = _batch(N)
+    st, M, m = util.settled_states(ref, "rodent_optimized", N, seed=8, iterations=(8, 8))
+    ctrl = torch.tensor(np.random.default_rng(1).uniform(-1, 1, (N, M.nu)), dtype=torch.float32, device=DEV)
+    mk = lambda: {k: torch.tensor(v, dtype=torch.float32, device=DEV).contiguous() for k, v in st.items()}
+    d = b.dims
+    dbg1 = torch.zeros(N, d.dbg_floats, device=DEV)
+    s1 = mk()
+    b.pipeline_step(s1, ctrl, 1, out=dict(debug=dbg1))
+    full = dict(cinert=torch.zeros(N, d.nbody * 10, device=DEV), cvel=torch.zeros(N, d.nbody * 6, device=DEV),
+                qfrc_actuator=torch.zeros(N, d.nv, device=DEV), xpos=torch.zeros(N, d.nbody * 3, device=DEV),
+                xmat=torch.zeros(N, d.nbody * 9, device=DEV), subtree_com=torch.zeros(N, 3, device=DEV),
+                debug=torch.zeros(N, d.dbg_floats, device=DEV), contact_dist=torch.zeros(N, d.ncon, device=DEV),
+                contact_pos=torch.zeros(N, d.ncon * 3, device=DEV), contact_frame=torch.zeros(N, d.ncon * 9, device=DEV))
+    s2 = mk()
+    b.pipeline_step(s2, ctrl, 1, out=full)
+    s3 = mk()
+    b.pipeline_step(s3, ctrl, 1, out=dict(contact_dist=torch.zeros(N, d.ncon, device=DEV)))      # debug instance, no dump buffer
+    s4 = mk()
+    b.pipeline_step(s4, ctrl, 1)                                                                   # production instance, out = NULL
+    torch.cuda.synchronize()
+    lay = b.debug_layout()
+    o, n = lay["kernarg_ok"]
+    assert (dbg1[:, o] == 1).all() and (full["debug"][:, o] == 1).all()
+    for k in s1:
+        assert torch.equal(s1[k], s2[k]) and torch.equal(s1[k], s3[k]), k
+        assert torch.isfinite(s4[k]).all()
+    f = lambda name: full["debug"][:, lay[name][0]:lay[name][0] + lay[name][1]]
+    assert torch.equal(full["contact_dist"], f("con_dist")) and torch.equal(full["contact_pos"], f("con_pos"))
+    assert torch.equal(full["contact_frame"], f("con_frame"))
+    assert torch.equal(full["xpos"], f("xpos")) and torch.equal(full["xmat"], f("xmat")) and torch.equal(full["cinert"], f("cinert"))
+    assert torch.equal(full["cvel"], f("cvel")) and torch.equal(full["qfrc_actuator"], f("qfrc_actuator"))
+    # contact geometry against the oracle (brax State.contact: dist, pos, frame)
+    for e in range(N):
+        dd = util.oracle_forward(ref, M, st, e, ctrl[e].cpu().numpy().astype(np.float64))
+        assert np.abs(full["contact_dist"][e].cpu().numpy() - dd.get("con_dist")).max() < 2e-6
+        assert np.abs(full["contact_pos"][e].cpu().numpy() - dd.get("con_pos")).max() < 2e-6
+        assert np.abs(full["contact_frame"][e].cpu().numpy() - dd.get("con_frame")).max() < 2e-6
+
+
+def test_env_contact_and_pipeline_outputs():
+    """`Rodent(..., pipeline_outputs=True, contact_outputs=True)`: brax-style State.contact fields and `sys` id tables."""
+    from rodent_amd import envs
+    env = envs.get_environment("rodent", track_pos=util.synthetic_track(), num_envs=4, xml_path="rodent_optimized.xml", iterations=8,
+                               ls_iterations=8, device=DEV, pipeline_outputs=True, contact_outputs=True)
+    s = env.step(env.reset(2), torch.zeros(4, env.action_size, device=DEV))
+    ps = s.pipeline_state
+    assert ps.contact_dist.shape == (4, 59) and ps.contact_pos.shape == (4, 59, 3) and ps.contact_frame.shape == (4, 59, 3, 3)
+    assert torch.isfinite(ps.contact_dist).all() and ps.xpos.shape == (4, 66, 3)
+    assert torch.allclose(ps.contact_frame[:, :, 0], torch.tensor([0.0, 0.0, 1.0], device=DEV).expand(4, 59, 3))     # floor normal
+    assert env.sys.contact_geom2[-5:].tolist() == [1, 62, 75, 89, 97] and env.sys.contact_link_idx[0].tolist() == [-1] * 59
+    lean = envs.get_environment("rodent", track_pos=util.synthetic_track(), num_envs=4, xml_path="rodent_optimized.xml", iterations=8,
+                                ls_iterations=8, device=DEV)
+    s2 = lean.step(lean.reset(2), torch.zeros(4, env.action_size, device=DEV))
+    assert s2.pipeline_state.cinert is None and s2.pipeline_state.contact_dist is None
+    assert torch.equal(s2.obs, s.obs) and torch.equal(s2.pipeline_state.qpos, ps.qpos)
