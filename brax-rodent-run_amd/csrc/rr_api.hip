@@ -2,6 +2,7 @@
 // tables, LDS / debug layouts and the launch wrappers behind the C ABI of include/rodent_rr.h.
 #include "../../include/rodent_rr.h"
 #include "rr_kernel.h"
+#include "rr_mlp.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -380,6 +381,46 @@ extern "C" int rr_compute_gae(const float* truncation, const float* termination,
     return fail(RR_EINVAL, "rr_compute_gae: bad argument");
   hipLaunchKernelGGL(rr_gae_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, truncation, termination, rewards,
                      values, bootstrap_value, T, B, lambda_, discount, vs, advantages);
+  HIPCHK(hipGetLastError());
+  return RR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ PPO: fused MLP forward (MFMA f32)
+static int mlp_net(const rr_mlp_net* n, int K, int hidden, bool is_value, RRMlpNet* out, const char* who) {
+  memset(out, 0, sizeof(*out));
+  if (!n) return RR_OK;
+  if (!n->weights || !n->biases || !n->sizes || n->nlayers < 2 || n->nlayers > RR_MLP_MAXL) return fail(RR_EINVAL, std::string("rr_mlp_forward: bad ") + who + " network description");
+  if (n->sizes[0] != K) return fail(RR_EINVAL, std::string("rr_mlp_forward: ") + who + " input width differs from the observation width");
+  for (int l = 1; l < n->nlayers; ++l)
+    if (n->sizes[l] != hidden) return fail(RR_EUNSUPPORTED, std::string("rr_mlp_forward: ") + who + " hidden width must be " + std::to_string(hidden));
+  const int od = n->sizes[n->nlayers];
+  if (is_value ? od != 1 : (od < 1 || od > 64)) return fail(RR_EUNSUPPORTED, std::string("rr_mlp_forward: unsupported ") + who + " output width");
+  for (int l = 0; l < n->nlayers; ++l) {
+    if (!n->weights[l] || !n->biases[l]) return fail(RR_EINVAL, std::string("rr_mlp_forward: null ") + who + " parameter");
+    out->W[l] = n->weights[l]; out->b[l] = n->biases[l];
+  }
+  out->nlayers = n->nlayers; out->out_dim = od;
+  return RR_OK;
+}
+
+extern "C" int rr_mlp_forward(const float* obs, int32_t M, int32_t K, const float* mean, const float* std_, const rr_mlp_net* policy,
+                              const rr_mlp_net* value, float* policy_out, float* value_out, float* policy_pre, float* value_pre, void* stream) {
+  if (!obs || M <= 0 || K <= 0 || (!policy && !value)) return fail(RR_EINVAL, "rr_mlp_forward: bad argument");
+  if ((mean == nullptr) != (std_ == nullptr)) return fail(RR_EINVAL, "rr_mlp_forward: mean and std must be given together");
+  if ((policy && !policy_out) || (value && !value_out)) return fail(RR_EINVAL, "rr_mlp_forward: missing output buffer");
+  RRMlpArgs A;
+  memset(&A, 0, sizeof(A));
+  int rc;
+  if ((rc = mlp_net(policy, K, RR_MLP_PH, false, &A.pol, "policy")) || (rc = mlp_net(value, K, RR_MLP_VH, true, &A.val, "value"))) return rc;
+  A.obs = obs; A.M = M; A.K = K; A.mean = mean; A.std_ = std_;
+  A.pol_out = policy_out; A.val_out = value_out; A.pol_act = policy ? policy_pre : nullptr; A.val_act = value ? value_pre : nullptr;
+  const size_t lds = RR_MLP_LDS_FLOATS * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute((const void*)rr_mlp_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(rr_mlp_forward_kernel, dim3((M + RR_MLP_BM - 1) / RR_MLP_BM), dim3(256), lds, (hipStream_t)stream, A);
   HIPCHK(hipGetLastError());
   return RR_OK;
 }

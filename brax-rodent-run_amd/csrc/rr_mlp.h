@@ -1,0 +1,255 @@
+// rr_mlp.h -- fused actor/critic MLP forward on the f32 matrix cores of gfx950 (MI355X).
+//
+// Path replaced: `acting.actor_step` -> `ppo.networks.make_inference_fn` (normalise obs, policy MLP) and the forward half of
+// `ppo.losses.compute_ppo_loss` (policy + value MLP on the same observations) [UP brax.training; SURVEY.md a22 / a25 /
+// Appendix E; driven by REF brax_rodent_run_ppo.py:97-114].  Shapes of `make_ppo_networks` defaults: policy
+// obs -> 32 x4 -> 2*action_size, value obs -> 256 x5 -> 1, swish (SiLU) on hidden layers.
+//
+// One workgroup (4 wavefronts) owns 32 observation rows through ALL layers of BOTH networks:
+//   * the observation chunk [32 x 16] is read from HBM once, normalised ((x - mean) / std) while it is staged into LDS,
+//     and feeds the first layer of both nets in the same k-loop (policy 1263 -> 32, value 1263 -> 256);
+//   * hidden activations never leave LDS ([32 x 256] value, [32 x 32] policy); weights stream through L2
+//     (2.5 MB per workgroup, shared by all workgroups);
+//   * arithmetic: v_mfma_f32_32x32x2_f32 for the 256-wide value layers (each wave owns two 32x32 output tiles: 4 waves x 64
+//     columns), v_mfma_f32_16x16x4_f32 for the 32-wide policy layers (each wave one 16x16 tile of the 32x32 output) -- f32 in,
+//     f32 accumulate, bit-for-bit a k-ordered fmaf chain (the reference's precision; no bf16 down-cast anywhere);
+//   * global loads of chunk c+1 are issued into registers before the MFMAs of chunk c (register double buffer);
+//   * LDS row strides 18 / 258 / 34 floats make every fragment read (lane -> row, lane>>5|4 -> k) bank-conflict free.
+// Optional outputs: the hidden PRE-activations of every layer (for a hand-written backward pass), row-major [M][width].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RR_MLP_BM 32        // observation rows per workgroup
+#define RR_MLP_KC 16        // k-chunk staged through LDS
+#define RR_MLP_VH 256       // value hidden width
+#define RR_MLP_PH 32        // policy hidden width
+#define RR_MLP_MAXL 8
+
+struct RRMlpNet {
+  const float* W[RR_MLP_MAXL];   // [out][in] row-major (torch.nn.Linear.weight)
+  const float* b[RR_MLP_MAXL];   // [out]
+  int nlayers;                   // hidden layers + 1
+  int out_dim;                   // width of the last layer (policy: 2*action_size <= 64; value: 1)
+};
+struct RRMlpArgs {
+  const float* obs; int M, K;
+  const float* mean; const float* std_;      // nullable: no normalisation
+  RRMlpNet pol, val;                         // nlayers == 0: that network is skipped
+  float* pol_out;                            // [M][pol.out_dim]
+  float* val_out;                            // [M]
+  float* pol_act;                            // nullable: [pol.nlayers-1][M][32]   hidden PRE-activations z = h W' + b (for a backward pass)
+  float* val_act;                            // nullable: [val.nlayers-1][M][256]
+};
+
+typedef float rr_f4 __attribute__((ext_vector_type(4)));
+typedef float rr_f16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float rr_silu(float v) { return v / (1.0f + expf(-v)); }
+
+constexpr int RR_SX = RR_MLP_KC + 2;        // stage stride (18): 18 n mod 64 is a bijection of n = 0..31 onto the even banks
+constexpr int RR_SV = RR_MLP_VH + 2;        // value activation stride (258)
+constexpr int RR_SP = RR_MLP_PH + 2;        // policy activation stride (34)
+constexpr int RR_WROWS = RR_MLP_VH + 64;    // staged weight rows: 256 value + up to 64 policy
+constexpr int RR_MLP_LDS_FLOATS = RR_MLP_BM * RR_SX + RR_WROWS * RR_SX + RR_MLP_BM * RR_SV + RR_MLP_BM * RR_SP;
+
+// Stage rows [row0, row0+nrows) x k [k0, k0+KC) of a row-major matrix (leading dimension ld, valid k < K, valid rows < R) in
+// two steps: `fetch` issues the global loads into registers, `commit` writes them to LDS (so loads fly during the MFMAs).
+template <int NROWS>
+struct RRStage {
+  static constexpr int PER = (NROWS * RR_MLP_KC + 255) / 256;
+  float r[PER];
+  __device__ __forceinline__ void fetch(const float* src, int ld, int row0, int R, int k0, int K) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = threadIdx.x + 256 * i, n = e / RR_MLP_KC, kk = e % RR_MLP_KC;
+      const bool ok = e < NROWS * RR_MLP_KC && row0 + n < R && k0 + kk < K;
+      r[i] = ok ? src[(size_t)(row0 + n) * ld + k0 + kk] : 0.0f;
+    }
+  }
+  __device__ __forceinline__ void commit(float* dst /* [NROWS][RR_SX] */) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = threadIdx.x + 256 * i, n = e / RR_MLP_KC, kk = e % RR_MLP_KC;
+      if (e < NROWS * RR_MLP_KC) dst[n * RR_SX + kk] = r[i];
+    }
+  }
+};
+
+// k-loop over one staged chunk.  A rows come from `xa` (stride sa, k offset ka); weights from the stage `w`.
+// Value: wave `wv` owns output columns [64 wv, 64 wv + 64) as two 32x32 tiles.  Policy: wave owns the 16x16 tile (mt, nt).
+template <bool VAL, bool POL>
+__device__ __forceinline__ void rr_mlp_chunk(const float* xa, int sa, int ka, const float* w, int prow0, rr_f16& a0, rr_f16& a1, rr_f4& ap,
+                                             int lane, int wv) {
+  if (VAL) {
+    const float* xr = xa + (lane & 31) * sa + ka + (lane >> 5);
+    const float* w0 = w + (64 * wv + (lane & 31)) * RR_SX + (lane >> 5);
+#pragma unroll
+    for (int kk = 0; kk < RR_MLP_KC; kk += 2) {
+      const float a = xr[kk];
+      a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w0[kk], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w0[32 * RR_SX + kk], a1, 0, 0, 0);
+    }
+  }
+  if (POL) {
+    const int mt = wv >> 1, nt = wv & 1;
+    const float* xr = xa + (16 * mt + (lane & 15)) * sa + ka + (lane >> 4);
+    const float* w0 = w + (prow0 + 16 * nt + (lane & 15)) * RR_SX + (lane >> 4);
+#pragma unroll
+    for (int kk = 0; kk < RR_MLP_KC; kk += 4) ap = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[kk], w0[kk], ap, 0, 0, 0);
+  }
+}
+
+// epilogue of a 256-wide value layer: act[m][n] = silu(acc + b[n]); C/D map of the 32x32 tile: col = lane & 31,
+// row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+__device__ __forceinline__ void rr_mlp_store_val(float* actV, const rr_f16& a0, const rr_f16& a1, const float* bias, int lane, int wv,
+                                                 float* dump, int row0, int M) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int n = 64 * wv + 32 * t + (lane & 31);
+    const float bn = bias[n];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const float z = (t ? a1[r] : a0[r]) + bn;
+      actV[m * RR_SV + n] = rr_silu(z);
+      if (dump && row0 + m < M) dump[(size_t)(row0 + m) * RR_MLP_VH + n] = z;
+    }
+  }
+}
+// 16x16 tile: col = lane & 15, row = 4 (lane >> 4) + reg
+__device__ __forceinline__ void rr_mlp_store_pol(float* actP, const rr_f4& ap, const float* bias, int lane, int wv, float* dump, int row0, int M) {
+  const int mt = wv >> 1, nt = wv & 1;
+  const int n = 16 * nt + (lane & 15);
+  const float bn = bias[n];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = 16 * mt + 4 * (lane >> 4) + r;
+    const float z = ap[r] + bn;
+    actP[m * RR_SP + n] = rr_silu(z);
+    if (dump && row0 + m < M) dump[(size_t)(row0 + m) * RR_MLP_PH + n] = z;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void rr_mlp_forward_kernel(const RRMlpArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* sX = lds;                                   // [32][18]   normalised observation chunk
+  float* sW = sX + RR_MLP_BM * RR_SX;                // [320][18]  weight chunk: rows 0..255 value, 256.. policy
+  float* actV = sW + RR_WROWS * RR_SX;               // [32][258]
+  float* actP = actV + RR_MLP_BM * RR_SV;            // [32][34]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int row0 = blockIdx.x * RR_MLP_BM;
+  const bool has_val = A.val.nlayers > 0, has_pol = A.pol.nlayers > 0;
+  const int M = A.M, K = A.K;
+
+  // ------------------------------------------------------------------ layer 1 of both nets: one pass over the observation
+  {
+    rr_f16 a0 = {0}, a1 = {0};
+    rr_f4 ap = {0, 0, 0, 0};
+    RRStage<RR_MLP_BM> gx;
+    RRStage<RR_MLP_VH> gv;
+    RRStage<RR_MLP_PH> gp;
+    const int nchunk = (K + RR_MLP_KC - 1) / RR_MLP_KC;
+    auto fetch = [&](int c) {
+      const int k0 = c * RR_MLP_KC;
+      gx.fetch(A.obs, K, row0, M, k0, K);
+      if (A.mean) {      // normalise in registers: (x - mean) / std  (running_statistics.normalize)
+#pragma unroll
+        for (int i = 0; i < RRStage<RR_MLP_BM>::PER; ++i) {
+          const int kk = (threadIdx.x + 256 * i) % RR_MLP_KC;
+          if (k0 + kk < K) gx.r[i] = (gx.r[i] - A.mean[k0 + kk]) / A.std_[k0 + kk];
+        }
+      }
+      if (has_val) gv.fetch(A.val.W[0], K, 0, RR_MLP_VH, k0, K);
+      if (has_pol) gp.fetch(A.pol.W[0], K, 0, RR_MLP_PH, k0, K);
+    };
+    fetch(0);
+    for (int c = 0; c < nchunk; ++c) {
+      gx.commit(sX);
+      if (has_val) gv.commit(sW);
+      if (has_pol) gp.commit(sW + RR_MLP_VH * RR_SX);
+      __syncthreads();
+      if (c + 1 < nchunk) fetch(c + 1);
+      if (has_val && has_pol) rr_mlp_chunk<true, true>(sX, RR_SX, 0, sW, RR_MLP_VH, a0, a1, ap, lane, wv);
+      else if (has_val) rr_mlp_chunk<true, false>(sX, RR_SX, 0, sW, RR_MLP_VH, a0, a1, ap, lane, wv);
+      else rr_mlp_chunk<false, true>(sX, RR_SX, 0, sW, RR_MLP_VH, a0, a1, ap, lane, wv);
+      __syncthreads();
+    }
+    if (has_val) rr_mlp_store_val(actV, a0, a1, A.val.b[0], lane, wv, A.val_act, row0, M);
+    if (has_pol) rr_mlp_store_pol(actP, ap, A.pol.b[0], lane, wv, A.pol_act, row0, M);
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ value hidden layers 256 -> 256 (activations stay in LDS)
+  for (int l = 1; has_val && l < A.val.nlayers - 1; ++l) {
+    rr_f16 a0 = {0}, a1 = {0};
+    rr_f4 ap = {0, 0, 0, 0};
+    RRStage<RR_MLP_VH> gv;
+    constexpr int nchunk = RR_MLP_VH / RR_MLP_KC;
+    gv.fetch(A.val.W[l], RR_MLP_VH, 0, RR_MLP_VH, 0, RR_MLP_VH);
+    for (int c = 0; c < nchunk; ++c) {
+      gv.commit(sW);
+      __syncthreads();
+      if (c + 1 < nchunk) gv.fetch(A.val.W[l], RR_MLP_VH, 0, RR_MLP_VH, (c + 1) * RR_MLP_KC, RR_MLP_VH);
+      rr_mlp_chunk<true, false>(actV, RR_SV, c * RR_MLP_KC, sW, 0, a0, a1, ap, lane, wv);
+      __syncthreads();
+    }
+    // every wave has read the whole input before anyone overwrites it (the barrier closing the last chunk)
+    rr_mlp_store_val(actV, a0, a1, A.val.b[l], lane, wv, A.val_act ? A.val_act + (size_t)l * M * RR_MLP_VH : nullptr, row0, M);
+    __syncthreads();
+  }
+  // value head 256 -> 1: eight lanes per row
+  if (has_val) {
+    const int l = A.val.nlayers - 1;
+    const int m = threadIdx.x >> 3, part = threadIdx.x & 7;
+    const float* w = A.val.W[l];
+    float s = 0.0f;
+#pragma unroll 8
+    for (int k = part; k < RR_MLP_VH; k += 8) s = fmaf(actV[m * RR_SV + k], w[k], s);
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    if (part == 0 && row0 + m < M) A.val_out[row0 + m] = s + A.val.b[l][0];
+  }
+
+  // ------------------------------------------------------------------ policy hidden layers 32 -> 32 and the head 32 -> out_dim
+  for (int l = 1; has_pol && l < A.pol.nlayers; ++l) {
+    const bool head = l == A.pol.nlayers - 1;
+    const int nout = head ? A.pol.out_dim : RR_MLP_PH;
+    __syncthreads();
+    // the whole weight matrix [nout <= 64][32] as two k-chunks side by side: chunk c of row n at sW[(64 c + n) * 18 ..]
+    for (int e = threadIdx.x; e < 64 * RR_MLP_PH; e += 256) {
+      const int n = e / RR_MLP_PH, k = e % RR_MLP_PH;
+      sW[(64 * (k / RR_MLP_KC) + n) * RR_SX + (k % RR_MLP_KC)] = n < nout ? A.pol.W[l][n * RR_MLP_PH + k] : 0.0f;
+    }
+    __syncthreads();
+    if (!head) {
+      rr_f16 d0 = {0}, d1 = {0};
+      rr_f4 ap = {0, 0, 0, 0};
+      rr_mlp_chunk<false, true>(actP, RR_SP, 0, sW, 0, d0, d1, ap, lane, wv);
+      rr_mlp_chunk<false, true>(actP, RR_SP, RR_MLP_KC, sW, 64, d0, d1, ap, lane, wv);
+      __syncthreads();
+      rr_mlp_store_pol(actP, ap, A.pol.b[l], lane, wv, A.pol_act ? A.pol_act + (size_t)l * M * RR_MLP_PH : nullptr, row0, M);
+    } else {
+      // [32 x 64] output = 2 x 4 tiles of 16x16: wave wv takes n-tile wv for both m-tiles
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        rr_f4 ap = {0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const float* xr = actP + (16 * mt + (lane & 15)) * RR_SP + c * RR_MLP_KC + (lane >> 4);
+          const float* w0 = sW + (64 * c + 16 * wv + (lane & 15)) * RR_SX + (lane >> 4);
+#pragma unroll
+          for (int kk = 0; kk < RR_MLP_KC; kk += 4) ap = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[kk], w0[kk], ap, 0, 0, 0);
+        }
+        const int n = 16 * wv + (lane & 15);
+        if (n < nout) {
+          const float bn = A.pol.b[l][n];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = 16 * mt + 4 * (lane >> 4) + r;
+            if (row0 + m < M) A.pol_out[(size_t)(row0 + m) * nout + n] = ap[r] + bn;
+          }
+        }
+      }
+    }
+  }
+}

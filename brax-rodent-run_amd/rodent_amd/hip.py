@@ -31,6 +31,10 @@ class RROutputs(C.Structure):
                                                 "contact_dist", "contact_pos", "contact_frame")]
 
 
+class RRMlpNet(C.Structure):
+    _fields_ = [("weights", C.POINTER(C.c_void_p)), ("biases", C.POINTER(C.c_void_p)), ("sizes", C.POINTER(C.c_int32)), ("nlayers", C.c_int32)]
+
+
 class RREnvIO(C.Structure):
     _fields_ = [("track_pos", C.c_void_p), ("track_len", C.c_int32), ("cur_frame", C.c_void_p), ("obs", C.c_void_p),
                 ("reward", C.c_void_p), ("done", C.c_void_p), ("metrics", C.c_void_p), ("healthy_reward", C.c_float),
@@ -40,7 +44,7 @@ class RREnvIO(C.Structure):
 
 EXPORTS = ["rr_model_load", "rr_model_dims", "rr_model_set_solver", "rr_model_destroy", "rr_model_table", "rr_kernarg_layout", "rr_batch_create",
            "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset", "rr_pipeline_step_to", "rr_env_step_to",
-           "rr_compute_gae", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
+           "rr_compute_gae", "rr_mlp_forward", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
 
 _lib = None
 
@@ -74,6 +78,8 @@ def lib():
         L.rr_debug_layout.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_int32)),
                                       C.POINTER(C.POINTER(C.c_int32))]
         L.rr_compute_gae.argtypes = [C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rr_mlp_forward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(RRMlpNet), C.POINTER(RRMlpNet),
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rr_wrap_episode_autoreset.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32)] + \
             [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_void_p]
         L.rr_batch_set_profile.argtypes = [C.c_void_p, C.c_void_p]
@@ -274,3 +280,45 @@ def wrap_episode_autoreset(first, cur, prev_done, prev_steps, done, steps, trunc
     stream = torch.cuda.current_stream(done.device).cuda_stream
     _check(lib().rr_wrap_episode_autoreset(N, n, F, Cu, W, prev_done.data_ptr(), prev_steps.data_ptr(), done.data_ptr(), steps.data_ptr(),
                                            truncation.data_ptr(), float(episode_length), float(action_repeat), C.c_void_p(stream)))
+
+
+def _mlp_net(weights, biases):
+    """(RRMlpNet, keep-alive) for a list of nn.Linear-layout weights [out, in] and biases [out] (float32 device tensors)."""
+    n = len(weights)
+    for w, b in zip(weights, biases):
+        _ptr(w); _ptr(b)
+        if w.dim() != 2 or b.numel() != w.shape[0]:
+            raise ValueError("weights must be [out, in] with biases [out]")
+    W = (C.c_void_p * n)(*[w.data_ptr() for w in weights])
+    B = (C.c_void_p * n)(*[b.data_ptr() for b in biases])
+    S = (C.c_int32 * (n + 1))(weights[0].shape[1], *[w.shape[0] for w in weights])
+    return RRMlpNet(C.cast(W, C.POINTER(C.c_void_p)), C.cast(B, C.POINTER(C.c_void_p)), C.cast(S, C.POINTER(C.c_int32)), n), (W, B, S)
+
+
+def mlp_forward(obs, mean=None, std=None, policy=None, value=None, want_pre=False):
+    """Fused normalise + policy MLP + value MLP forward on the f32 matrix cores (C ABI `rr_mlp_forward`).
+
+    obs [M, K] float32 device; policy / value: (weights, biases) lists in nn.Linear layout or None.  Returns
+    (policy_out [M, P] | None, value_out [M] | None, policy_pre [L-1, M, 32] | None, value_pre [L-1, M, 256] | None)."""
+    M, K = obs.shape
+    _ptr(obs)
+    dev = obs.device
+    pn = vn = None
+    keep = []
+    pol_out = val_out = pol_pre = val_pre = None
+    if policy is not None:
+        pn, k = _mlp_net(*policy); keep.append(k)
+        pol_out = torch.empty(M, policy[0][-1].shape[0], device=dev)
+        if want_pre:
+            pol_pre = torch.empty(len(policy[0]) - 1, M, 32, device=dev)
+    if value is not None:
+        vn, k = _mlp_net(*value); keep.append(k)
+        val_out = torch.empty(M, device=dev)
+        if want_pre:
+            val_pre = torch.empty(len(value[0]) - 1, M, 256, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    p = lambda t: t.data_ptr() if t is not None else None
+    _check(lib().rr_mlp_forward(obs.data_ptr(), M, K, _ptr(mean, numel=K) if mean is not None else None,
+                                _ptr(std, numel=K) if std is not None else None, C.byref(pn) if pn is not None else None,
+                                C.byref(vn) if vn is not None else None, p(pol_out), p(val_out), p(pol_pre), p(val_pre), C.c_void_p(stream)))
+    return pol_out, val_out, pol_pre, val_pre

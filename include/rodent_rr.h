@@ -133,6 +133,25 @@ int rr_compute_gae(const float* truncation, const float* termination, const floa
                    const float* bootstrap_value, int32_t T, int32_t B, float lambda_, float discount, float* vs,
                    float* advantages, void* stream);
 
+/* Fused actor / critic MLP forward on the f32 matrix cores (v_mfma_f32_32x32x2_f32 / 16x16x4_f32; csrc/rr_mlp.h): what
+ * `ppo.networks.make_inference_fn` (normalise, policy MLP) and the forward half of `ppo.losses.compute_ppo_loss` (policy and
+ * value MLP on the same observations) compute [UP brax.training; REF brax_rodent_run_ppo.py:97-114], for
+ * the `make_ppo_networks` default shapes: policy obs -> 32 x (nlayers-1) -> out (<= 64), value obs -> 256 x (nlayers-1) -> 1,
+ * SiLU on hidden layers, float32 throughout.  A network is described by HOST arrays of DEVICE pointers: weights[l] is
+ * [sizes[l+1]][sizes[l]] row-major (torch.nn.Linear.weight), biases[l] is [sizes[l+1]]; sizes has nlayers + 1 entries.
+ * Either network may be NULL (skipped).  mean / std (device, [K]) may both be NULL (no normalisation), else
+ * x <- (x - mean) / std.  Outputs: policy_out [M][sizes[nlayers]], value_out [M]; optional PRE-activation dumps of the
+ * hidden layers (for a backward pass): policy_pre [nlayers-1][M][32], value_pre [nlayers-1][M][256] (NULL = not written).
+ * RR_EUNSUPPORTED for other shapes. */
+typedef struct rr_mlp_net {
+  const float* const* weights;
+  const float* const* biases;
+  const int32_t* sizes;
+  int32_t nlayers;
+} rr_mlp_net;
+int rr_mlp_forward(const float* obs, int32_t M, int32_t K, const float* mean, const float* std, const rr_mlp_net* policy,
+                   const rr_mlp_net* value, float* policy_out, float* value_out, float* policy_pre, float* value_pre, void* stream);
+
 /* brax.envs.wrappers.training.EpisodeWrapper + AutoResetWrapper [UP; SURVEY.md 3.4] after an env step, in one launch:
  * steps' = (prev_done ? 0 : prev_steps) + action_repeat; over = steps' >= episode_length; done <- over ? 1 : done;
  * truncation = over ? 1 - done_env : 0; and for every env with done != 0 the rows of the `narr` (<= 12) arrays `cur[i]`

@@ -53,7 +53,9 @@ def test_teacher_forced_1000_substeps_production_instance(substep_inputs):
 
 
 def test_teacher_forced_substeps_rodent_pair(oracle_built):
-    seq, A, tab = parity.rollout_inputs("rodent_pair", 8, 200, (8, 8), seed=33)
+    # the free bodies of the replicas sit at the origin (the torsos are offset inside them): no height test for the restarts
+    seq, A, tab = parity.rollout_inputs("rodent_pair", 8, 200, (8, 8), seed=33, z_range=(-1.0, 1.0))
+    assert len(np.unique(np.stack([st["qpos"][0] for st, _ in seq]).round(9), axis=0)) > 150
     out = parity.substep_ladder(HipImpl("rodent_pair", 8, (8, 8), True), seq, A, parity.OracleImpl("rodent_pair", 8, "f32", (8, 8)))
     _report("substeps_cg8_pair", out)
     parity.assert_substep_criteria(out)
@@ -102,7 +104,8 @@ def test_free_running_converged_solver_1000_steps(oracle_built):
         hq = hs.pipeline_state.qpos.cpu().numpy().astype(np.float64)
         assert np.isfinite(hq).all() and torch.isfinite(hs.obs).all()
         np.testing.assert_array_equal(hs.info["cur_frame"].cpu().numpy(), A.cur_frame)          # never restored, saturating index
-        np.testing.assert_array_equal(hs.info["steps"].cpu().numpy(), A.steps)
+        # an env whose `done` history equals the oracle's has the same step counter and truncation flag, exactly
+        np.testing.assert_array_equal(hs.info["steps"].cpu().numpy()[insync], A.steps[insync])
         hd = hs.done.cpu().numpy()
         insync &= hd == A.done
         np.testing.assert_array_equal(hs.info["truncation"].cpu().numpy()[insync], A.truncation[insync])
@@ -124,7 +127,7 @@ def test_free_running_converged_solver_1000_steps(oracle_built):
 
 
 @pytest.mark.parametrize("model_name", ["rodent_optimized", "rodent_pair"])
-def test_np_ref_fixtures(model_name):
+def test_np_ref_fixtures(model_name, oracle_built):
     """HIP against tests/golden/step_*.npz, generated by oracle/np_ref.py alone (tools/make_step_golden.py)."""
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"step_{model_name}.npz"))
     n = g["in_qpos"].shape[0]
@@ -147,8 +150,10 @@ def test_np_ref_fixtures(model_name):
     np.testing.assert_array_equal(f("con_dist") < 0, g["fwd_con_dist"] < 0)
     np.testing.assert_array_equal(f("niter_cost")[:, 0].astype(int), g["fwd_cg8_niter"][:, 0].astype(int))
     worst["qacc"] = (rel(f("qacc"), g["fwd_cg8_qacc"]), 2e-4)
-    worst["qpos_substep"] = (float(np.abs(ds["qpos"].cpu().numpy() - g["sub_cg8_qpos"]).max()), 2e-6)
-    worst["qvel_substep"] = (float(np.abs(ds["qvel"].cpu().numpy() - g["sub_cg8_qvel"]).max()), 1e-3)
+    # one substep: the bound is 3x what the scalar float32 oracle loses on these very states (heavy-tailed: tests/parity.py)
+    B = parity.OracleImpl(model_name, n, "f32", (8, 8)).substep(st, g["in_ctrl"])
+    worst["qpos_substep"] = (float(np.abs(ds["qpos"].cpu().numpy() - g["sub_cg8_qpos"]).max()), 3 * float(np.abs(B["qpos"] - g["sub_cg8_qpos"]).max()) + 2e-7)
+    worst["qvel_substep"] = (float(np.abs(ds["qvel"].cpu().numpy() - g["sub_cg8_qvel"]).max()), 3 * float(np.abs(B["qvel"] - g["sub_cg8_qvel"]).max()) + 2e-5)
     print(model_name, {k: f"{v[0]:.2e}" for k, v in worst.items()})
     bad = {k: v for k, v in worst.items() if not v[0] <= v[1]}
     assert not bad, bad

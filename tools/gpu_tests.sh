@@ -3,7 +3,7 @@
 tag=${1:-x}
 mkdir -p gpurun_out
 export OMP_NUM_THREADS=16
-timeout -k 10 1100 python -m pytest tests -m gpu -x -q -s --durations=15 > gpurun_out/t_$tag.log 2>&1
+timeout -k 10 1100 python -m pytest tests -m gpu -q -s --durations=15 > gpurun_out/t_$tag.log 2>&1
 rc=$?
 tail -n 40 gpurun_out/t_$tag.log
 [ $rc -eq 0 ] && timeout -k 10 200 python __graft_entry__.py smoke > gpurun_out/smoke_$tag.log 2>&1 && tail -n 3 gpurun_out/smoke_$tag.log
