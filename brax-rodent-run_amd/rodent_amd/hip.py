@@ -138,7 +138,9 @@ class Model:
 
 
 class Batch:
-    """`num_envs` environments of one model on one GPU; all work goes to torch's current stream."""
+    """`num_envs` environments of one model on one GPU.  All launches go to the stream that was torch's current stream on
+    `device` WHEN THE BATCH WAS CREATED (the C ABI binds the stream at rr_batch_create); create the batch inside the
+    `torch.cuda.stream(...)` context it should run on."""
 
     def __init__(self, model: Model, num_envs: int, device: Optional[torch.device] = None):
         if not torch.cuda.is_available():

@@ -30,7 +30,7 @@ def compute_gae(truncation, termination, rewards, values, bootstrap_value, lambd
 
 def compute_ppo_loss(policy_logits, baseline, bootstrap_value, data: Dict[str, torch.Tensor], dist, entropy_cost=1e-4,
                      discounting=0.9, reward_scaling=1.0, gae_lambda=0.95, clipping_epsilon=0.3,
-                     normalize_advantage=True, generator=None) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+                     normalize_advantage=True, generator=None, advantage_stats_fn=None) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
     """`data` leaves are time-major [T, B(, ...)]: reward, discount, truncation, raw_action, log_prob."""
     rewards = data["reward"] * reward_scaling
     truncation = data["truncation"]
@@ -40,7 +40,11 @@ def compute_ppo_loss(policy_logits, baseline, bootstrap_value, data: Dict[str, t
     vs, advantages = compute_gae(truncation, termination, rewards, baseline.detach(), bootstrap_value.detach(),
                                  lambda_=gae_lambda, discount=discounting)
     if normalize_advantage:
-        advantages = (advantages - advantages.mean()) / (advantages.std(unbiased=False) + 1e-8)
+        if advantage_stats_fn is not None:          # global minibatch statistics (extension; the reference is device-local)
+            mean, std = advantage_stats_fn(advantages)
+            advantages = (advantages - mean) / (std + 1e-8)
+        else:
+            advantages = (advantages - advantages.mean()) / (advantages.std(unbiased=False) + 1e-8)
     rho_s = torch.exp(target_action_log_probs - behaviour_action_log_probs)
     surrogate_loss1 = rho_s * advantages
     surrogate_loss2 = torch.clamp(rho_s, 1 - clipping_epsilon, 1 + clipping_epsilon) * advantages

@@ -9,6 +9,7 @@ once per training step (RCCL over xGMI; gloo in the CPU tests).
 """
 from __future__ import annotations
 
+import copy
 import math
 import logging
 import os
@@ -20,7 +21,7 @@ import torch
 
 from .... import jax_random
 from ....envs import wrappers
-from ... import acting, distributed as D, networks as ppo_networks_mod, running_statistics
+from ... import acting, distributed as D, fused_mlp, networks as ppo_networks_mod, running_statistics
 from . import losses as ppo_losses
 
 
@@ -58,6 +59,7 @@ def train(
     network_factory: Callable = ppo_networks_mod.make_ppo_networks,
     progress_fn: Callable = lambda *args: None,
     normalize_advantage: bool = True,
+    global_advantage_normalization: bool = False,
     eval_env=None,
     policy_params_fn: Callable = lambda *args: None,
     randomization_fn=None,
@@ -67,6 +69,9 @@ def train(
     """PPO training.  Returns (make_policy, params=(normalizer_params, policy_params), metrics).
 
     `max_training_steps` (extension) stops after that many training steps (benchmarks / tests).
+    `global_advantage_normalization` (extension, default off = the reference's behaviour: advantages are normalised over
+    the rank-local minibatch): normalise with the mean / variance of the GLOBAL minibatch instead, one
+    3-float all-reduce {n, sum a, sum a^2} per minibatch (the north star's "advantage-normalisation all-reduce").
     """
     assert batch_size * num_minibatches % num_envs == 0
     if randomization_fn is not None:
@@ -113,7 +118,12 @@ def train(
     # One process on a GPU: the minibatch update (gather, normalise, both MLPs forward + backward, GAE kernel, fused Adam) is
     # captured once in a HIP graph and replayed -- ~70 small launches per update otherwise leave the GPU idle between them
     # (half of the learner's wall time at the launcher's sizes).  RR_PPO_GRAPH=0 keeps the eager path.
-    use_graph = device.type == "cuda" and process_count == 1 and os.environ.get("RR_PPO_GRAPH", "1") == "1"
+    # Several ranks: the same capture split in two around the gradient all-reduce -- graph A (gather .. backward), the RCCL
+    # all-reduce of the flat gradient buffer issued eagerly, graph B (fused Adam) -- so a multi-GPU run keeps the replayed
+    # learner instead of falling back to ~70 eager launches per minibatch.  (The optional global advantage normalisation
+    # puts a collective inside the loss: that mode runs eagerly.)
+    use_graph = (device.type == "cuda" and os.environ.get("RR_PPO_GRAPH", "1") == "1"
+                 and not (global_advantage_normalization and process_count > 1))
     optimizer = torch.optim.Adam(params, lr=learning_rate, betas=(0.9, 0.999), eps=1e-8, fused=(device.type == "cuda"),
                                  capturable=use_graph)
     normalizer_params = running_statistics.init_state(env.observation_size, device)
@@ -141,19 +151,44 @@ def train(
         if device.type == "cuda":
             torch.cuda.synchronize(device)
 
-    gstate = {"graph": None, "calls": 0, "idx": None, "norm": None, "metrics": None, "failed": False}
+    gstate = {"graph": None, "graph_b": None, "calls": 0, "idx": None, "norm": None, "metrics": None, "failed": False}
 
-    def eager_update(data, idx, nparams):
-        obs = normalize(data["obs"][idx].transpose(0, 1), nparams)     # [T+1, B, obs]
+    def adv_stats(adv):
+        """mean / std of the advantages over the GLOBAL minibatch (all ranks): one all-reduce of {n, sum, sum of squares}."""
+        st = torch.stack([torch.tensor(float(adv.numel()), device=adv.device), adv.sum(), (adv * adv).sum()])
+        D.all_reduce_sum_(st)
+        mean = st[1] / st[0]
+        return mean, torch.sqrt(torch.clamp(st[2] / st[0] - mean * mean, min=0.0))
+
+    # forward of both networks on the hand-written f32-MFMA kernel (one launch, observation tile read once for both nets,
+    # normalisation fused) with an explicit backward; nn.Linear path for other shapes / CPU (RR_FUSED_MLP=0 forces it)
+    use_fused = (device.type == "cuda" and os.environ.get("RR_FUSED_MLP", "1") == "1"
+                 and fused_mlp.fusable(policy_net, fused_mlp.POLICY_HIDDEN, 64) and fused_mlp.fusable(value_net, fused_mlp.VALUE_HIDDEN, 1))
+
+    def fwd_bwd(data, idx, nparams):
         mbd = {k: data[k][idx].transpose(0, 1) for k in ("raw_action", "log_prob", "reward", "discount", "truncation")}
-        policy_logits = policy_net(obs[:T])
-        values = value_net(obs).squeeze(-1)
+        if use_fused:
+            raw = data["obs"][idx].transpose(0, 1)                         # [T+1, B, obs], time-major gather
+            B_ = raw.shape[1]
+            mean, std = (nparams.mean, nparams.std) if normalize_observations else (None, None)
+            logits_all, values_all = fused_mlp.actor_critic(raw.reshape((T + 1) * B_, -1), mean, std, policy_net, value_net)
+            policy_logits = logits_all[:T * B_].reshape(T, B_, -1)        # the bootstrap row's logits carry no gradient
+            values = values_all.reshape(T + 1, B_)
+        else:
+            obs = normalize(data["obs"][idx].transpose(0, 1), nparams)     # [T+1, B, obs]
+            policy_logits = policy_net(obs[:T])
+            values = value_net(obs).squeeze(-1)
         loss, m = ppo_losses.compute_ppo_loss(
             policy_logits, values[:T], values[T], mbd, dist, entropy_cost=entropy_cost, discounting=discounting,
             reward_scaling=reward_scaling, gae_lambda=gae_lambda, clipping_epsilon=clipping_epsilon,
-            normalize_advantage=normalize_advantage, generator=gen)
+            normalize_advantage=normalize_advantage, generator=gen,
+            advantage_stats_fn=adv_stats if (global_advantage_normalization and process_count > 1) else None)
         flat.zero_()
         loss.backward()
+        return m
+
+    def eager_update(data, idx, nparams):
+        m = fwd_bwd(data, idx, nparams)
         flat.pmean_()                            # jax.lax.pmean(grads, 'i')
         optimizer.step()
         return m
@@ -172,17 +207,28 @@ def train(
                 if hasattr(g, "register_generator_state"):
                     g.register_generator_state(gen)
                 torch.cuda.synchronize(device)
-                with torch.cuda.graph(g):
-                    gstate["metrics"] = eager_update(data, gstate["idx"], gstate["norm"] if normalize_observations else normalizer_params)
+                npar = gstate["norm"] if normalize_observations else normalizer_params
+                if process_count == 1:
+                    with torch.cuda.graph(g):
+                        gstate["metrics"] = eager_update(data, gstate["idx"], npar)
+                else:                            # capture records, it does not run: both halves are replayed below
+                    with torch.cuda.graph(g):
+                        gstate["metrics"] = fwd_bwd(data, gstate["idx"], npar)
+                    gb = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gb):
+                        optimizer.step()
+                    gstate["graph_b"] = gb
                 gstate["graph"] = g
             except Exception as e:               # keep training on the eager path
                 gstate["failed"] = True
+                gstate["graph"] = gstate["graph_b"] = None
                 logging.warning("PPO update graph capture failed (%s); continuing eagerly", e)
                 return eager_update(data, idx, normalizer_params)
-            gstate["graph"].replay()
-            return gstate["metrics"]
         gstate["idx"].copy_(idx)
         gstate["graph"].replay()
+        if gstate["graph_b"] is not None:
+            flat.pmean_()
+            gstate["graph_b"].replay()
         return gstate["metrics"]
 
     def training_step():
@@ -247,7 +293,9 @@ def train(
             else:
                 metrics = dict(training_metrics)
             progress_fn(current_step, metrics)
-            policy_params_fn(current_step, make_policy, params_tuple(normalizer_params, policy_net, normalize_observations))
+            # callbacks get a SNAPSHOT (the live network keeps training)
+            policy_params_fn(current_step, make_policy, params_tuple(normalizer_params.clone(), copy.deepcopy(policy_net).requires_grad_(False),
+                                                                     normalize_observations))
         if stop:
             break
 

@@ -1,7 +1,8 @@
 """PPO networks of `brax.training.agents.ppo.networks.make_ppo_networks` (defaults): policy MLP
 obs -> 32 x4 -> 2*action_size, value MLP obs -> 256 x5 -> 1, swish on hidden layers,
 lecun_uniform kernels, zero biases; `NormalTanhDistribution(min_std=1e-3)`.
-The GEMMs run on the matrix cores through rocBLAS/hipBLASLt; nothing else in the path uses MFMA."""
+On a GPU with these default shapes the forward passes run on the hand-written f32-MFMA kernel (`fused_mlp`, C ABI
+`rr_mlp_forward`); other shapes / CPU tensors use the nn.Linear path (rocBLAS/hipBLASLt)."""
 from __future__ import annotations
 
 import math
@@ -89,17 +90,31 @@ def make_inference_fn(ppo_networks: PPONetworks):
     """`make_policy(params, deterministic)` -> `policy(obs, key) -> (action, extras)` [UP ppo.networks]."""
     from . import running_statistics
 
+    import copy
+    import os
+    from . import fused_mlp
+
     def make_policy(params, deterministic: bool = False):
         normalizer_params, policy_params = params[0], params[1]
         net = ppo_networks.policy_network
-        if policy_params is not None and policy_params is not net:
-            net.load_state_dict(policy_params) if isinstance(policy_params, dict) else None
+        if isinstance(policy_params, nn.Module):
+            net = policy_params                              # the live training network or a snapshot of it
+        elif isinstance(policy_params, dict):                # a checkpoint: load into a COPY, never into the training network
+            net = copy.deepcopy(ppo_networks.policy_network)
+            net.load_state_dict(policy_params)
+        elif policy_params is not None:
+            raise TypeError(f"policy params must be an nn.Module or a state dict, got {type(policy_params).__name__}")
         dist = ppo_networks.parametric_action_distribution
+        fused = os.environ.get("RR_FUSED_MLP", "1") == "1" and fused_mlp.fusable(net, fused_mlp.POLICY_HIDDEN, 64)
 
         @torch.no_grad()
         def policy(observations, key_sample=None):
-            x = observations if normalizer_params is None else running_statistics.normalize(observations, normalizer_params)
-            logits = net(x)
+            if fused and observations.is_cuda and observations.dtype == torch.float32 and observations.dim() == 2:
+                mean, std = (None, None) if normalizer_params is None else (normalizer_params.mean, normalizer_params.std)
+                logits = fused_mlp.policy_logits(observations, mean, std, net)        # normalise + MLP: one MFMA launch
+            else:
+                x = observations if normalizer_params is None else running_statistics.normalize(observations, normalizer_params)
+                logits = net(x)
             if deterministic:
                 return dist.mode(logits), {}
             raw = dist.sample_no_postprocessing(logits, key_sample)

@@ -104,3 +104,32 @@ def test_env_step_matches_oracle_rodent_new(oracle_built):
     out = parity.envstep_ladder(HipEnvImpl(N, (8, 8), track, "rodent_new"), seq, A, parity.OracleEnvImpl("rodent_new", N, "f32", (8, 8), track), tab)
     print(out)
     parity.check_quantiles(out["quantiles"], parity.ENV_FLOORS)
+
+
+def test_config5_rodent_pair_at_4096_envs():
+    """BASELINE config 5 at its size: rodent_pair.xml (nv 146, 114 contacts), 4096 envs, physics only: finite, deterministic
+    across launches, and env e of the big batch equals the same state stepped in a batch of 16 (parity of that instance against
+    the oracle: tests/test_gpu_ladder.py::test_teacher_forced_substeps_rodent_pair)."""
+    from rodent_amd import assets, hip, mjcf
+    N = 4096
+    path = assets.asset_path("rodent_pair")
+    m = mjcf.load_blob(path)
+    b = hip.Batch(hip.Model(path, 8, 8), N, torch.device("cuda:0"))
+    d = b.dims
+    g = torch.Generator(device="cuda:0"); g.manual_seed(2)
+    q = torch.tensor(np.tile(m["qpos0"], (N, 1)), dtype=torch.float32, device="cuda:0") + (torch.rand(N, d.nq, device="cuda:0", generator=g) * 2 - 1) * 0.01
+    st = dict(qpos=q, qvel=torch.zeros(N, d.nv, device="cuda:0"), act=torch.zeros(N, d.na, device="cuda:0"),
+              qacc_warmstart=torch.zeros(N, d.nv, device="cuda:0"))
+    b.pipeline_init(st)
+    for _ in range(5):
+        b.pipeline_step(st, torch.rand(N, d.nu, device="cuda:0", generator=g) * 2 - 1, 10)
+    ctrl = torch.rand(N, d.nu, device="cuda:0", generator=g) * 2 - 1
+    s1, s2 = {k: v.clone() for k, v in st.items()}, {k: v.clone() for k, v in st.items()}
+    b.pipeline_step(s1, ctrl, 10); b.pipeline_step(s2, ctrl, 10)
+    small = hip.Batch(b.model, 16, torch.device("cuda:0"))
+    s3 = {k: v[100:116].clone() for k, v in st.items()}
+    small.pipeline_step(s3, ctrl[100:116].contiguous(), 10)
+    torch.cuda.synchronize()
+    for k in st:
+        assert torch.isfinite(s1[k]).all(), k
+        assert torch.equal(s1[k], s2[k]) and torch.equal(s1[k][100:116], s3[k]), k

@@ -62,3 +62,71 @@ def test_gae_kernel_matches_torch_scan():
     got_vs, got_adv = losses.compute_gae(*(x.cuda() for x in (trunc, term, r, v, boot)), lambda_=0.95, discount=0.97)
     torch.testing.assert_close(got_vs.cpu(), want_vs, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(got_adv.cpu(), want_adv, rtol=1e-5, atol=1e-5)
+
+
+def test_config3_full_size_training_step(monkeypatch):
+    """BASELINE config 3 at its size: ONE training step of the launcher's PPO configuration [REF brax_rodent_run_ppo.py:97-114]
+    at num_envs = batch_size = 2048 (64 unrolls x 10 steps = 1 310 720 env-steps, 512 minibatch updates of [11 x 2048 x 1263]
+    through the fused f32-MFMA forward): finite losses, and the HIP-graph replay gives the eager run's parameters bit for bit."""
+    from rodent_amd import envs
+    from rodent_amd.training.agents.ppo import train as ppo
+    out, losses = {}, {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RR_PPO_GRAPH", mode)
+        env = envs.get_environment("rodent", track_pos=util.synthetic_track(), num_envs=2048, xml_path="rodent_optimized.xml",
+                                   terminate_when_unhealthy=True, solver="cg", iterations=8, ls_iterations=8, device="cuda:0")
+        log, timing = [], []
+        _, params, metrics = ppo.train(environment=env, num_timesteps=500_000_000, num_evals=100, reward_scaling=1, episode_length=150,
+                                       normalize_observations=True, action_repeat=1, unroll_length=10, num_minibatches=64,
+                                       num_updates_per_batch=8, discounting=0.97, learning_rate=5e-5, entropy_cost=1e-3, num_envs=2048,
+                                       batch_size=2048, seed=0, num_eval_envs=0, max_training_steps=1, timing_fn=timing.append,
+                                       progress_fn=lambda n, m: log.append((n, m)))
+        assert timing[0]["env_steps"] == 1_310_720
+        m = log[-1][1]
+        for k in ("training/total_loss", "training/policy_loss", "training/v_loss", "training/entropy_loss"):
+            assert math.isfinite(float(m[k])), (k, m[k])
+        assert float(params[0].count) == 1_310_720            # the normaliser saw every transition of the step
+        out[mode] = [p.detach().clone() for p in params[1].parameters()]
+        losses[mode] = float(m["training/total_loss"])
+        print(f"config 3, graph={mode}: rollout {timing[0]['rollout_s']:.2f} s, learner {timing[0]['learner_s']:.2f} s, "
+              f"{timing[0]['env_steps'] / (timing[0]['rollout_s'] + timing[0]['learner_s']):.0f} env-steps/s")
+    for a, b in zip(out["1"], out["0"]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def _two_rank_worker(rank, world, port, out, graph):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), RR_PPO_GRAPH=graph)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rodent_amd import envs
+        from rodent_amd.training.agents.ppo import train as ppo
+        torch.cuda.set_device(0)
+        env = envs.get_environment("rodent", track_pos=util.synthetic_track(), num_envs=64, xml_path="rodent_optimized.xml",
+                                   iterations=8, ls_iterations=8, device="cuda:0")
+        _, params, _ = ppo.train(environment=env, num_timesteps=128 * 4 * 4 * 3, episode_length=150, num_envs=128, batch_size=128,
+                                 num_minibatches=4, unroll_length=4, num_updates_per_batch=3, num_evals=1, num_eval_envs=0,
+                                 learning_rate=5e-5, entropy_cost=1e-3, discounting=0.97, normalize_observations=True, seed=3)
+        vec = torch.cat([p.detach().reshape(-1) for p in params[1].parameters()]).cpu()
+        out[rank] = (vec.numpy().copy(), params[0].mean.cpu().numpy().copy(), float(params[0].count))
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("graph", ["1", "0"])
+def test_two_ranks_share_the_gpu_through_the_hip_env(graph):
+    """Rehearsal of the multi-GPU learner on one GPU: two ranks (gloo; RCCL refuses two ranks on one device) each step 64 real HIP
+    envs; gradients and normaliser statistics are all-reduced, so both end with IDENTICAL parameters.  graph = 1: the
+    two-graph learner (capture A: gather .. backward | all-reduce | capture B: Adam) that multi-rank runs use."""
+    import os
+    import numpy as np
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 29500 + (os.getpid() + int(graph)) % 2000
+    mp.spawn(_two_rank_worker, args=(2, port, out, graph), nprocs=2, join=True)
+    (p0, m0, c0), (p1, m1, c1) = out[0], out[1]
+    assert np.isfinite(p0).all()
+    np.testing.assert_array_equal(p0, p1)
+    np.testing.assert_array_equal(m0, m1)
+    assert c0 == c1 == 128 * 4 * 4 * 3

@@ -6,5 +6,8 @@ export OMP_NUM_THREADS=16
 timeout -k 10 1100 python -m pytest tests -m gpu -q -s --durations=15 > gpurun_out/t_$tag.log 2>&1
 rc=$?
 tail -n 40 gpurun_out/t_$tag.log
-[ $rc -eq 0 ] && timeout -k 10 200 python __graft_entry__.py smoke > gpurun_out/smoke_$tag.log 2>&1 && tail -n 3 gpurun_out/smoke_$tag.log
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 200 python __graft_entry__.py smoke > gpurun_out/smoke_$tag.log 2>&1
+rc=$?
+tail -n 3 gpurun_out/smoke_$tag.log
 exit $rc
