@@ -11,7 +11,10 @@ import os
 from . import mjcf
 
 ASSET_DIR = os.environ.get("RR_ASSETS") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets")
-MODELS = ("rodent_optimized", "rodent_new", "rodent_pair", "rodent_0")
+MODELS = ("rodent_optimized", "rodent_new", "rodent_pair", "rodent_0", "rodent_cpu")
+# rodent_cpu.xml (BASELINE config 1, CPU plumbing): ~4.3 k self-collision pairs of primitives that are not implemented are
+# dropped at compile time (contacts off); its blob carries no kernel tables (hip_supported = 0)
+_COMPILE_KW = {"rodent_cpu": dict(contacts="supported_only")}
 
 
 def asset_path(name: str) -> str:
@@ -31,7 +34,7 @@ def build_assets(xml_dir: str, names=MODELS, force: bool = False):
         if not os.path.exists(src):
             continue
         if force or not os.path.exists(dst) or os.path.getmtime(dst) < _compiler_mtime():
-            mjcf.save_blob(mjcf.compile_mjcf(src), dst)
+            mjcf.save_blob(mjcf.compile_mjcf(src, **_COMPILE_KW.get(n, {})), dst)
             built.append(dst)
     return built
 
@@ -46,7 +49,7 @@ def resolve_model(xml_path: str) -> str:
         os.makedirs(ASSET_DIR, exist_ok=True)
         dst = asset_path(stem)
         if not os.path.exists(dst) or os.path.getmtime(dst) < os.path.getmtime(xml_path):
-            mjcf.save_blob(mjcf.compile_mjcf(xml_path), dst)
+            mjcf.save_blob(mjcf.compile_mjcf(xml_path, **_COMPILE_KW.get(stem, {})), dst)
         return dst
     dst = asset_path(stem)
     if not os.path.exists(dst):

@@ -271,11 +271,14 @@ def _parse_replicate(elem, parent, defaults, suffix):
 
 
 def compile_mjcf(xml_path: str, *, iterations: int = 6, ls_iterations: int = 6,
-                 solver: str = "cg") -> Dict[str, np.ndarray]:
+                 solver: str = "cg", contacts: str = "strict") -> Dict[str, np.ndarray]:
     """Compile an MJCF file into a dict of numpy tables (MuJoCo field names + engine tables).
 
     `iterations` / `ls_iterations` / `solver` mirror the `opt` overrides the reference applies
-    after loading [REF Rodent_Env_Brax.py:42-49].
+    after loading [REF Rodent_Env_Brax.py:42-49].  `contacts`: "strict" raises on a geom pair whose collision primitive is
+    not implemented (everything but plane - sphere / capsule / ellipsoid); "supported_only" drops such pairs and records
+    their number in `ndropped_pairs` (rodent_cpu.xml: ~4.3 k capsule-capsule / ellipsoid self-collision pairs -- the
+    config-1 plumbing case runs with contacts off).
     """
     root = ET.parse(xml_path).getroot()
     comp = {}
@@ -464,10 +467,26 @@ def compile_mjcf(xml_path: str, *, iterations: int = 6, ls_iterations: int = 6,
             if not any(body_weldid[c.id] == b.id and body_mass[c.id] > MJ_MINVAL for c in bodies[1:]):
                 raise ValueError(f"moving body {b.name} has no mass")
 
+    # ---- fixed tendons [REF models/rodent_cpu.xml:505-560]: length = sum coef_i * qpos[joint_i] (MuJoCo <tendon><fixed>)
+    name2jnt = {n: i for i, n in enumerate(jnt_names)}
+    ten_names, ten_adr, ten_num, wrap_jnt, wrap_coef = [], [], [], [], []
+    ten = root.find("tendon")
+    if ten is not None:
+        for t in ten:
+            if t.tag != "fixed":
+                raise ValueError(f"tendon <{t.tag}> not supported (fixed tendons only)")
+            ten_names.append(t.attrib["name"]); ten_adr.append(len(wrap_jnt)); ten_num.append(0)
+            for w in t:
+                if w.tag != "joint":
+                    raise ValueError("fixed tendons wrap joints only")
+                if jnt_type[name2jnt[w.attrib["joint"]]] != HINGE:
+                    raise ValueError("fixed tendon over a non-hinge joint not supported")
+                wrap_jnt.append(name2jnt[w.attrib["joint"]]); wrap_coef.append(float(w.attrib["coef"])); ten_num[-1] += 1
+    name2ten = {n: i for i, n in enumerate(ten_names)}
+
     # ---- actuators
     act = root.find("actuator")
-    trn_jnt, gain0, bias, tau, ctrlrange, ctrllimited, act_names = [], [], [], [], [], [], []
-    name2jnt = {n: i for i, n in enumerate(jnt_names)}
+    trn_type, trn_id, gain0, bias, tau, ctrlrange, ctrllimited, act_names = [], [], [], [], [], [], [], []
     specs = []
     if act is not None:
         for a in act:
@@ -475,9 +494,6 @@ def compile_mjcf(xml_path: str, *, iterations: int = 6, ls_iterations: int = 6,
                 raise ValueError(f"actuator <{a.tag}> not supported")
             g = defaults.get("general", a.attrib.get("class"))
             _apply_attrs(g, a)
-            if "tendon" in a.attrib:
-                raise ValueError("tendon transmission not supported")
-            jn = a.attrib["joint"]
             if g["dyntype"] != "filter" or g["gaintype"] != "fixed" or g["biastype"] != "affine":
                 raise ValueError("only filter/fixed/affine general actuators are supported")
             if g["forcelimited"]:
@@ -485,19 +501,33 @@ def compile_mjcf(xml_path: str, *, iterations: int = 6, ls_iterations: int = 6,
             cl = g["ctrllimited"]
             if cl is None:
                 cl = not (g["ctrlrange"][0] == 0 and g["ctrlrange"][1] == 0)
-            specs.append((jn, a.attrib.get("name", jn), g, int(cl)))
+            if "tendon" in a.attrib:
+                specs.append(("tendon", a.attrib["tendon"], a.attrib.get("name", a.attrib["tendon"]), g, int(cl)))
+            else:
+                specs.append(("joint", a.attrib["joint"], a.attrib.get("name", a.attrib["joint"]), g, int(cl)))
         # <replicate> suffixes joint names but the rodent_pair actuator block sits outside it and
         # names the un-suffixed joints [REF models/rodent_pair.xml:545-576]: drive every replica,
         # ordered [all actuators of replica 0][all of replica 1]....
-        sfxs = [""] if all(jn in name2jnt for jn, _, _, _ in specs) else list(defaults.replica_suffixes)
+        sfxs = [""] if all((n in name2jnt) if k == "joint" else (n in name2ten) for k, n, _, _, _ in specs) else list(defaults.replica_suffixes)
         for sfx in sfxs:
-            for jn, nm, g, cl in specs:
-                if jn + sfx not in name2jnt:
-                    raise ValueError(f"actuator joint {jn + sfx} not found")
-                trn_jnt.append(name2jnt[jn + sfx]); gain0.append(g["gainprm"][0]); bias.append(g["biasprm"][:3])
+            for kind, tn, nm, g, cl in specs:
+                table = name2jnt if kind == "joint" else name2ten
+                if tn + sfx not in table:
+                    raise ValueError(f"actuator {kind} {tn + sfx} not found")
+                trn_type.append(0 if kind == "joint" else 3); trn_id.append(table[tn + sfx])      # mjtTrn: 0 joint, 3 tendon
+                gain0.append(g["gainprm"][0]); bias.append(g["biasprm"][:3])
                 tau.append(g["dynprm"][0]); ctrlrange.append(g["ctrlrange"]); ctrllimited.append(cl)
                 act_names.append(nm + sfx)
-    nu = len(trn_jnt)
+    nu = len(trn_id)
+    # sparse transmission: actuator u acts on the dofs mom_dof[madr[u]:madr[u+1]] with the coefficients mom_coef
+    # (`actuator_moment` rows; a joint transmission is one entry of gear 1)
+    madr, mom_jnt, mom_coef = [0], [], []
+    for tt, ti in zip(trn_type, trn_id):
+        if tt == 0:
+            mom_jnt.append(ti); mom_coef.append(1.0)
+        else:
+            mom_jnt += wrap_jnt[ten_adr[ti]:ten_adr[ti] + ten_num[ti]]; mom_coef += wrap_coef[ten_adr[ti]:ten_adr[ti] + ten_num[ti]]
+        madr.append(len(mom_jnt))
 
     # ---- excludes
     excl = set()
@@ -530,20 +560,28 @@ def compile_mjcf(xml_path: str, *, iterations: int = 6, ls_iterations: int = 6,
         geom_priority=i32(geom_priority), geom_friction=f64(geom_friction, (ngeom, 3)),
         geom_solref=f64(geom_solref, (ngeom, 2)), geom_solimp=f64(geom_solimp, (ngeom, 5)),
         geom_solmix=f64(geom_solmix), geom_margin=f64(geom_margin), geom_gap=f64(geom_gap),
-        actuator_trnid=i32(trn_jnt), actuator_gainprm0=f64(gain0), actuator_biasprm=f64(bias, (nu, 3)),
+        actuator_trnid=i32(trn_id), actuator_trntype=i32(trn_type), actuator_momentadr=i32(madr),
+        actuator_moment_jnt=i32(mom_jnt), actuator_moment_coef=f64(mom_coef), ntendon=i32(len(ten_names)),
+        actuator_gainprm0=f64(gain0), actuator_biasprm=f64(bias, (nu, 3)),
         actuator_dynprm0=f64(tau), actuator_ctrlrange=f64(ctrlrange, (nu, 2)), actuator_ctrllimited=i32(ctrllimited),
         # options: MuJoCo defaults (the rodent XMLs have no <option>) + the reference's overrides
         opt_timestep=f64(0.002), opt_gravity=f64([0, 0, -9.81]), opt_tolerance=f64(1e-8),
         opt_ls_tolerance=f64(0.01), opt_impratio=f64(1.0), opt_iterations=i32(iterations),
         opt_ls_iterations=i32(ls_iterations), opt_solver=i32({"cg": 1, "newton": 2}[solver.lower()]),
     )
-    m["_names"] = dict(body=[b.name for b in bodies], joint=jnt_names, geom=geom_names, actuator=act_names)
+    m["_names"] = dict(body=[b.name for b in bodies], joint=jnt_names, geom=geom_names, actuator=act_names, tendon=ten_names)
     m["_exclude"] = excl
     _set_const(m)
-    _collision_tables(m)
+    _collision_tables(m, contacts)
     _engine_tables(m)
-    from .ktables import build_kernel_tables
-    m.update(build_kernel_tables(m))
+    # the fused HIP kernel serves the floor-contact, joint-actuated, free-floating rodents; other models (rodent_cpu.xml:
+    # tendon transmissions, welded root) compile for the CPU path only and their blob carries no kernel tables, so
+    # rr_model_load refuses them
+    hip_ok = (not any(trn_type)) and int(m["ncon"]) > 0 and any(t == FREE for t in jnt_type)
+    m["hip_supported"] = np.int32(hip_ok)
+    if hip_ok:
+        from .ktables import build_kernel_tables
+        m.update(build_kernel_tables(m))
     return m
 
 
@@ -662,7 +700,7 @@ def _set_const(m):
 
 
 # ----------------------------------------------------------------------------- collision tables
-def _collision_tables(m):
+def _collision_tables(m, contacts="strict"):
     """Static geom-pair list + per-contact mixed parameters, as MJX builds at trace time.
 
     Pair filter, type ordering and parameter mixing restate `mjx collision_driver` (SURVEY A-4):
@@ -694,9 +732,13 @@ def _collision_tables(m):
                 continue
             pairs.append((int(t1), int(t2), a, b))
     pairs.sort()
-    for t1, t2, _, _ in pairs:
-        if t1 != PLANE or t2 not in (SPHERE, CAPSULE, ELLIPSOID):
+    ok = [p for p in pairs if p[0] == PLANE and p[1] in (SPHERE, CAPSULE, ELLIPSOID)]
+    m["ndropped_pairs"] = np.int32(len(pairs) - len(ok))
+    if len(ok) != len(pairs):
+        if contacts != "supported_only":
+            t1, t2 = next((p[0], p[1]) for p in pairs if p not in ok)
             raise ValueError(f"collision type pair ({t1},{t2}) not supported (plane-sphere/capsule/ellipsoid only)")
+        pairs = ok
     con_geom1, con_geom2, con_kind = [], [], []   # kind: 0 sphere, 1 capsule +axis end, 2 capsule -axis end, 3 ellipsoid
     fr, sr, si = [], [], []
     for t1, t2, g1, g2 in pairs:
@@ -772,9 +814,12 @@ def _engine_tables(m):
     # limited joints (hinge) in joint order
     lim = [j for j in range(int(m["njnt"])) if m["jnt_limited"][j]]
     m["limit_jnt"] = np.asarray(lim, np.int32)
-    # actuator -> qpos / dof address
-    m["actuator_qposadr"] = m["jnt_qposadr"][m["actuator_trnid"]].astype(np.int32)
-    m["actuator_dofadr"] = m["jnt_dofadr"][m["actuator_trnid"]].astype(np.int32)
+    # actuator -> qpos / dof addresses of its transmission entries (joint transmission: one entry)
+    m["actuator_moment_qposadr"] = m["jnt_qposadr"][m["actuator_moment_jnt"]].astype(np.int32)
+    m["actuator_moment_dofadr"] = m["jnt_dofadr"][m["actuator_moment_jnt"]].astype(np.int32)
+    first = m["actuator_momentadr"][:-1]
+    m["actuator_qposadr"] = m["actuator_moment_qposadr"][first].astype(np.int32)      # (first entry: the joint of a joint transmission)
+    m["actuator_dofadr"] = m["actuator_moment_dofadr"][first].astype(np.int32)
     # obs size of the reference env [REF Rodent_Env_Brax.py:147-158]
     m["obs_dim"] = np.int32(int(m["nq"]) + nv + 16 * (nb - 1) + nv + 3)
 

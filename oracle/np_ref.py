@@ -226,12 +226,16 @@ def smooth_forces(m: Model, d: Data):
     d.qfrc_passive = passive
     c = np.clip(d.ctrl, t["actuator_ctrlrange"][:, 0], t["actuator_ctrlrange"][:, 1])
     d.act_dot = (c - d.act) / np.maximum(t["actuator_dynprm0"], MINVAL)
-    length = d.qpos[t["actuator_qposadr"]]
-    vel = d.qvel[t["actuator_dofadr"]]
+    # transmission: dense moment matrix [nu, nv] built from the sparse entries (joint: gear 1; fixed tendon: its coefficients)
+    moment = np.zeros((m.nu, m.nv)); moment_q = np.zeros((m.nu, m.nq))
+    for u in range(m.nu):
+        for e in range(t["actuator_momentadr"][u], t["actuator_momentadr"][u + 1]):
+            moment[u, t["actuator_moment_dofadr"][e]] += t["actuator_moment_coef"][e]
+            moment_q[u, t["actuator_moment_qposadr"][e]] += t["actuator_moment_coef"][e]
+    length, vel = moment_q @ d.qpos, moment @ d.qvel
     force = t["actuator_gainprm0"] * d.act + t["actuator_biasprm"][:, 0] + t["actuator_biasprm"][:, 1] * length \
         + t["actuator_biasprm"][:, 2] * vel
-    d.qfrc_actuator = np.zeros(m.nv)
-    np.add.at(d.qfrc_actuator, t["actuator_dofadr"], force)
+    d.qfrc_actuator = moment.T @ force
     d.qfrc_smooth = d.qfrc_passive - d.qfrc_bias + d.qfrc_actuator
     d.qacc_smooth = cho_solve(d.Mchol, d.qfrc_smooth)
 

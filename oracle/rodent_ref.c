@@ -73,13 +73,14 @@ typedef struct ref_model {
   const int32_t *dof_bodyid, *dof_jntid, *dof_parentid, *dof_Madr, *dof_depth;
   const int32_t *geom_bodyid, *con_geom1, *con_geom2, *con_kind, *con_body2, *limit_jnt;
   const int32_t *actuator_qposadr, *actuator_dofadr;
+  const int32_t *actuator_momentadr, *actuator_moment_qposadr, *actuator_moment_dofadr; /* sparse transmission (joint: 1 entry, fixed tendon: its joints) */
   /* real tables (converted copies) */
   real *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia;
   real *jnt_pos, *jnt_axis, *jnt_stiffness, *jnt_range, *jnt_solref, *jnt_solimp;
   real *dof_armature, *dof_damping, *dof_invweight0, *qpos0, *qpos_spring;
   real *geom_pos, *geom_quat, *geom_size;
   real *con_friction, *con_solref, *con_solimp, *con_invweight;
-  real *gain0, *biasprm, *tau, *ctrlrange;
+  real *gain0, *biasprm, *tau, *ctrlrange, *actuator_moment_coef;
 } ref_model;
 
 static const blob_entry* find(const ref_model* m, const char* name) {
@@ -147,12 +148,13 @@ ref_model* ref_model_load(const char* path) {
   IT(dof_bodyid); IT(dof_jntid); IT(dof_parentid); IT(dof_Madr); IT(dof_depth);
   IT(geom_bodyid); IT(con_geom1); IT(con_geom2); IT(con_kind); IT(con_body2); IT(limit_jnt);
   IT(actuator_qposadr); IT(actuator_dofadr);
+  IT(actuator_momentadr); IT(actuator_moment_qposadr); IT(actuator_moment_dofadr);
 #define RT(x) m->x = rtab(m, #x)
   RT(body_pos); RT(body_quat); RT(body_ipos); RT(body_iquat); RT(body_mass); RT(body_inertia);
   RT(jnt_pos); RT(jnt_axis); RT(jnt_stiffness); RT(jnt_range); RT(jnt_solref); RT(jnt_solimp);
   RT(dof_armature); RT(dof_damping); RT(dof_invweight0); RT(qpos0); RT(qpos_spring);
   RT(geom_pos); RT(geom_quat); RT(geom_size);
-  RT(con_friction); RT(con_solref); RT(con_solimp); RT(con_invweight);
+  RT(con_friction); RT(con_solref); RT(con_solimp); RT(con_invweight); RT(actuator_moment_coef);
   /* unit quaternions / axes are unit only to float32 round-off in the blob: renormalise them in the oracle's arithmetic
    * (MuJoCo normalises them in double at compile time), so that formulations that treat a non-unit vector differently
    * (oracle/np_ref.py) agree to double round-off */
@@ -690,11 +692,17 @@ static void fwd_actuation(const ref_model* m, ref_data* d) {
   for (int u = 0; u < m->nu; u++) {
     real c = FMIN(FMAX(d->ctrl[u], m->ctrlrange[2 * u]), m->ctrlrange[2 * u + 1]);
     d->act_dot[u] = (c - d->act[u]) / FMAX(m->tau[u], MINVAL);
-    real len = d->qpos[m->actuator_qposadr[u]];
-    real vel = d->qvel[m->actuator_dofadr[u]];
+    /* transmission [UP mjx smooth.transmission]: length = sum coef * qpos, velocity = sum coef * qvel (joint: one entry, gear 1;
+     * fixed tendon [REF models/rodent_cpu.xml:505-560]: its joints), force mapped back through the same coefficients */
+    real len = 0, vel = 0;
+    for (int e = m->actuator_momentadr[u]; e < m->actuator_momentadr[u + 1]; e++) {
+      len += m->actuator_moment_coef[e] * d->qpos[m->actuator_moment_qposadr[e]];
+      vel += m->actuator_moment_coef[e] * d->qvel[m->actuator_moment_dofadr[e]];
+    }
     real f = m->gain0[u] * d->act[u] + m->biasprm[3 * u] + m->biasprm[3 * u + 1] * len + m->biasprm[3 * u + 2] * vel;
     d->actuator_force[u] = f;
-    d->qfrc_actuator[m->actuator_dofadr[u]] += f;
+    for (int e = m->actuator_momentadr[u]; e < m->actuator_momentadr[u + 1]; e++)
+      d->qfrc_actuator[m->actuator_moment_dofadr[e]] += m->actuator_moment_coef[e] * f;
   }
 }
 static void fwd_acceleration(const ref_model* m, ref_data* d) {

@@ -1,0 +1,74 @@
+"""BASELINE config 1: `Rodent_Env_Brax.step()` with num_envs = 4 on rodent_cpu.xml, CPU (plumbing, no GPU).
+
+rodent_cpu.xml [REF models/rodent_cpu.xml] has no free joint and no floor, 8 fixed tendons driving 8 of its 38 actuators, and
+~4.3 k self-collision pairs of primitives this build does not implement.  What is exercised: the MJCF
+compiler on that file (dims, tendon transmission tables), the env reset / step arithmetic on the CPU oracle for 4 envs with
+contacts off (shapes, finite outputs, determinism, joint limits active), the tendon transmission in BOTH CPU formulations
+(C oracle: sparse entries; np_ref: dense moment matrix), and that the HIP library refuses this model instead of mis-running it.
+Deviation, stated: contacts are OFF for this model (ndropped_pairs recorded in the blob); the env's `qpos[:3] = track_pos`
+and `q[2]` health test act on hinge angles here, exactly as the reference code would."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import np_ref
+from rodent_amd import assets, hip, mjcf
+from tests import util
+from tests.oracle_env import OracleRodent
+
+
+def test_compiled_dims_and_tendon_tables():
+    m = mjcf.load_blob(assets.asset_path("rodent_cpu"))
+    got = {k: int(m[k]) for k in ("nbody", "nq", "nv", "nu", "ngeom", "nM", "ntendon", "ncon", "nlimit", "hip_supported")}
+    assert got == dict(nbody=66, nq=67, nv=67, nu=38, ngeom=100, nM=696, ntendon=8, ncon=0, nlimit=67, hip_supported=0)
+    assert 4000 < int(m["ndropped_pairs"]) < 4600
+    adr = m["actuator_momentadr"]
+    assert (np.diff(adr)[:8] == [2, 2, 2, 3, 2, 2, 12, 12]).all() and (np.diff(adr)[8:] == 1).all()      # [REF models/rodent_cpu.xml:505-560]
+    for u in range(6):          # lumbar / cervical tendons: coefficients sum to 1
+        assert abs(m["actuator_moment_coef"][adr[u]:adr[u + 1]].sum() - 1) < 1e-6
+    if os.path.exists("/root/reference/models/rodent_cpu.xml"):
+        c = mjcf.compile_mjcf("/root/reference/models/rodent_cpu.xml", contacts="supported_only")
+        assert c["_names"]["tendon"][0] == "lumbar_extend" and c["_names"]["actuator"][8] == "hip_L_supinate"
+        with pytest.raises(ValueError, match="not supported"):
+            mjcf.compile_mjcf("/root/reference/models/rodent_cpu.xml")                                   # strict mode names the gap
+
+
+def test_env_step_four_envs_on_the_cpu(oracle_built):
+    track = util.synthetic_track()
+    runs = []
+    for rep in range(2):
+        env = OracleRodent("rodent_cpu", 4, "f32", (6, 6), track, episode_length=150)      # the env class' default solver setting
+        obs = env.reset(0)
+        assert obs.shape == (4, 1244) and np.isfinite(obs).all()
+        rng = np.random.default_rng(0)
+        for t in range(20):
+            obs = env.step(rng.uniform(-1, 1, (4, 38)))
+            assert obs.shape == (4, 1244) and np.isfinite(obs).all() and np.isfinite(env.reward).all()
+        assert (env.cur_frame == env.cur_frame[0] * 0 + env.cur_frame).all() and env.done.shape == (4,)
+        runs.append((obs.copy(), env.state()["qpos"].copy()))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])           # deterministic
+    assert np.abs(runs[0][1]).max() < 3.5                                                                # joint limits hold the pose
+
+
+def test_tendon_transmission_in_both_formulations(oracle_built):
+    ref = oracle_built
+    st, M, tab = util.settled_states(ref, "rodent_cpu", 3, seed=5, iterations=(8, 8))
+    m = np_ref.Model(tab, 8, 8)
+    rng = np.random.default_rng(1)
+    for e in range(3):
+        ctrl = rng.uniform(-1, 1, M.nu)
+        c = util.oracle_forward(ref, M, st, e, ctrl)
+        d = np_ref.Data(m)
+        d.qpos, d.qvel, d.act, d.qacc_warmstart = (st[k][e].copy() for k in ("qpos", "qvel", "act", "qacc_warmstart"))
+        d.ctrl = ctrl.copy()
+        np_ref.forward(m, d)
+        for k in ("qfrc_actuator", "qfrc_bias", "qacc_smooth", "efc_D", "efc_aref", "qacc"):
+            a, b = getattr(d, k), c.get(k)
+            assert np.abs(a - b).max() <= 1e-9 * max(np.abs(b).max(), 1e-30), k
+        assert np.count_nonzero(c.get("qfrc_actuator")) > 38          # tendon actuators spread over several dofs
+
+
+def test_hip_library_refuses_the_model():
+    with pytest.raises(RuntimeError, match="blob lacks"):
+        hip.Model(assets.asset_path("rodent_cpu"))
