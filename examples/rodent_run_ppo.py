@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, "brax-rodent-run_amd"))
 import numpy as np
 import torch
 
-from rodent_amd import envs
+from rodent_amd import envs, preprocessing, rollout
 from rodent_amd.io import model
 from rodent_amd.training.agents.ppo import train as ppo
 
@@ -33,7 +33,9 @@ def main():
     ap.add_argument("--eval-every", type=int, default=5_000_000)
     ap.add_argument("--envs-per-gpu", type=int, default=1024)          # [REF :43] 1024 * n_gpus
     ap.add_argument("--xml", default="./models/rodent_new.xml")        # [REF Rodent_Env_Brax.py:16]
-    ap.add_argument("--clip", default=None, help=".npy with the reference clip root positions [T,3]; synthetic line if absent")
+    ap.add_argument("--clip", default=None, help="reference clip: .npz / .h5 written by preprocessing.save_reference_clip (clip name "
+                    "--clip-name) or .npy with the root positions [T,3]; a synthetic line if absent")
+    ap.add_argument("--clip-name", default="84")
     ap.add_argument("--max-training-steps", type=int, default=None)
     args = ap.parse_args()
 
@@ -49,7 +51,9 @@ def main():
         "batch_size": args.envs_per_gpu * n_gpus, "learning_rate": 5e-5, "terminate_when_unhealthy": True,
         "solver": "cg", "iterations": 8, "ls_iterations": 8, "vision": False,
     }
-    if args.clip and os.path.exists(args.clip):
+    if args.clip and os.path.exists(args.clip) and not args.clip.endswith(".npy"):
+        track_pos = np.asarray(preprocessing.load_reference_clip(args.clip, args.clip_name).position[0])     # reference_clip.position [REF :84]
+    elif args.clip and os.path.exists(args.clip):
         track_pos = np.load(args.clip)
     else:   # the reference clip (clips/84.p) is not distributed: straight line at 0.2 m/s, torso rest height
         t = np.arange(250)
@@ -75,9 +79,17 @@ def main():
         metrics["num_steps"] = num_steps
         print(json.dumps({k: (float(v) if np.isscalar(v) else v) for k, v in metrics.items()}), flush=True)
 
+    eval_env = env.with_num_envs(1)                  # the launcher's un-vmapped jit_reset / jit_step pair [REF :93-94]
+    ref_clip = preprocessing.ReferenceClip(position=track_pos, quaternion=np.tile([1.0, 0, 0, 0], (len(track_pos), 1)),
+                                           joints=np.zeros((len(track_pos), env.sys.nq - 7)))
+
     def policy_params_fn(num_steps, make_policy, params, model_path=model_path):
+        """Checkpoint + the 500-step evaluation rollout paired with the reference clip [REF brax_rodent_run_ppo.py:135-191];
+        the qpos pairs are saved instead of rendered (mujoco.Renderer / wandb are out of scope)."""
         os.makedirs(model_path, exist_ok=True)
         model.save_params(f"{model_path}/{num_steps}", params)
+        qposes = rollout.eval_rollout(eval_env, make_policy, params, steps=500, seed=0)
+        rollout.save_rollout(f"{model_path}/{num_steps}_rollout.npz", rollout.qpos_pairs(ref_clip, qposes), eval_env.dt, qposes)
 
     make_inference_fn, params, _ = train_fn(environment=env, progress_fn=progress, policy_params_fn=policy_params_fn)
     if int(os.environ.get("RANK", "0")) == 0:
