@@ -1,6 +1,6 @@
 """`rodent_amd.envs`: mirror of the `brax.envs` registry the launcher uses
 [REF brax_rodent_run_ppo.py:57,82-90]."""
-from .base import PipelineEnv, PipelineState, State
+from .base import Contact, PipelineEnv, PipelineState, State
 from .rodent import Rodent
 from . import wrappers
 

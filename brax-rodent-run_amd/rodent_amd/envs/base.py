@@ -50,6 +50,25 @@ class PipelineState:
 
 
 @dataclasses.dataclass
+class Contact:
+    """brax `State.contact` / `mjx.Data.contact` with the fields the reference's notebook shows [NB mjcf.ipynb:917-921]:
+    per-step geometry from the kernel (`contact_outputs=True`), static parameters and integer ids from the loaded model
+    (C ABI `rr_model_table`).  Leading env axis on the per-step fields."""
+    dist: torch.Tensor            # [N, ncon]
+    pos: torch.Tensor             # [N, ncon, 3]
+    frame: torch.Tensor           # [N, ncon, 3, 3]
+    includemargin: torch.Tensor   # [ncon] (0: the rodent models use no margin)
+    friction: torch.Tensor        # [ncon, 5]
+    solref: torch.Tensor          # [ncon, 2]
+    solreffriction: torch.Tensor  # [ncon, 2] (0)
+    solimp: torch.Tensor          # [ncon, 5]
+    geom1: torch.Tensor           # [ncon] int32
+    geom2: torch.Tensor           # [ncon] int32
+    link_idx: tuple               # (geom_bodyid[geom1] - 1, geom_bodyid[geom2] - 1), int32 [ncon] each
+    elasticity: torch.Tensor      # [ncon] (0)
+
+
+@dataclasses.dataclass
 class State:
     """Environment state for training and inference (brax.envs.base.State)."""
     pipeline_state: Optional[PipelineState]
@@ -132,6 +151,19 @@ class PipelineEnv:
             out.update(contact_dist=torch.empty(N, s.ncon, device=dev), contact_pos=torch.empty(N, s.ncon, 3, device=dev),
                        contact_frame=torch.empty(N, s.ncon, 3, 3, device=dev))
         return out
+
+    def contact(self, pipeline_state: PipelineState) -> Contact:
+        """The brax-style `Contact` of a pipeline state produced with `contact_outputs=True`."""
+        if pipeline_state.contact_dist is None:
+            raise ValueError("build the env with contact_outputs=True to get the contact geometry")
+        m, dev, nc = self.sys.model, self.device, self.sys.ncon
+        t = lambda name, w: torch.from_numpy(m.table(name).reshape(nc, w) if w > 1 else m.table(name)).to(dev)
+        i32 = lambda a: torch.from_numpy(a.astype("int32")).to(dev)
+        z = torch.zeros(nc, device=dev)
+        return Contact(dist=pipeline_state.contact_dist, pos=pipeline_state.contact_pos, frame=pipeline_state.contact_frame,
+                       includemargin=z, friction=t("con_friction", 5), solref=t("con_solref", 2), solreffriction=torch.zeros(nc, 2, device=dev),
+                       solimp=t("con_solimp", 5), geom1=i32(self.sys.contact_geom1), geom2=i32(self.sys.contact_geom2),
+                       link_idx=(i32(self.sys.contact_link_idx[0]), i32(self.sys.contact_link_idx[1])), elasticity=z.clone())
 
     def pipeline_init(self, q: torch.Tensor, qd: torch.Tensor) -> PipelineState:
         N, s, dev = self.num_envs, self.sys, self.device

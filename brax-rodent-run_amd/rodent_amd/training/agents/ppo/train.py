@@ -22,6 +22,7 @@ import torch
 from .... import jax_random
 from ....envs import wrappers
 from ... import acting, distributed as D, fused_mlp, networks as ppo_networks_mod, running_statistics
+from ...types import PPONetworkParams, TrainingState
 from . import losses as ppo_losses
 
 
@@ -65,10 +66,12 @@ def train(
     randomization_fn=None,
     max_training_steps: Optional[int] = None,
     timing_fn: Optional[Callable] = None,
+    return_training_state: bool = False,
 ):
     """PPO training.  Returns (make_policy, params=(normalizer_params, policy_params), metrics).
 
     `max_training_steps` (extension) stops after that many training steps (benchmarks / tests).
+    `return_training_state` (extension): also return the final `TrainingState` (optimizer, params, normaliser, env_steps).
     `global_advantage_normalization` (extension, default off = the reference's behaviour: advantages are normalised over
     the rank-local minibatch): normalise with the mean / variance of the GLOBAL minibatch instead, one
     3-float all-reduce {n, sum a, sum a^2} per minibatch (the north star's "advantage-normalisation all-reduce").
@@ -129,6 +132,8 @@ def train(
     normalizer_params = running_statistics.init_state(env.observation_size, device)
     normalize = running_statistics.normalize if normalize_observations else (lambda x, y: x)
     make_policy = ppo_networks_mod.make_inference_fn(ppo_network)
+    training_state = TrainingState(optimizer_state=optimizer, params=PPONetworkParams(policy=policy_net, value=value_net),
+                                   normalizer_params=normalizer_params, env_steps=torch.zeros((), dtype=torch.int32))
 
     def current_params():
         return (normalizer_params if normalize_observations else None, policy_net)
@@ -253,6 +258,8 @@ def train(
                 metrics = minibatch_update(data, idx)
         sync()
         t2 = time.time()
+        training_state.normalizer_params = normalizer_params
+        training_state.env_steps += env_step_per_training_step          # int32, as upstream
         if timing_fn is not None:
             timing_fn({"rollout_s": t1 - t0, "learner_s": t2 - t1, "env_steps": env_step_per_training_step})
         return {f"training/{k}": float(v) for k, v in metrics.items()}
@@ -308,7 +315,8 @@ def train(
         torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
         torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
         assert torch.allclose(lo, hi, rtol=1e-5, atol=1e-6), "parameters diverged across ranks"
-    return make_policy, params_tuple(normalizer_params, policy_net, normalize_observations), metrics
+    out = (make_policy, params_tuple(normalizer_params, policy_net, normalize_observations), metrics)
+    return out + (training_state,) if return_training_state else out
 
 
 def params_tuple(normalizer_params, policy_net, normalize_observations: bool):

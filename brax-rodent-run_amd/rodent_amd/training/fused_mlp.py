@@ -5,8 +5,9 @@ Replaces, for the `make_ppo_networks` default shapes (policy obs -> 32 x4 -> 2*a
 the ~40 library launches of `normalize -> policy_net -> value_net` in `ppo.losses.compute_ppo_loss`'s forward
 [UP brax.training.agents.ppo.losses; SURVEY.md a22 / a25] by ONE launch that reads the observation tile once for both
 networks.  The kernel also writes the hidden pre-activations, from which `backward` forms the parameter gradients with plain
-matrix products (the same GEMMs autograd would record; rocBLAS/hipBLASLt): dW_l = delta_l' h_{l-1},
-delta_{l-1} = (delta_l W_l) * silu'(z_{l-1}).
+matrix products (rocBLAS/hipBLASLt): dW_l = delta_l' h_{l-1},
+delta_{l-1} = silu_backward(delta_l W_l, z_{l-1}); the first layer's dW uses the raw observations and folds the normaliser
+in afterwards, so the normalised copy of the minibatch is never written.
 """
 from __future__ import annotations
 
@@ -30,11 +31,6 @@ def fusable(mlp, hidden: int, max_out: int) -> bool:
             and ls[0].weight.is_cuda and ls[0].weight.dtype == torch.float32)
 
 
-def _dsilu(z):
-    s = torch.sigmoid(z)
-    return s * (1 + z * (1 - s))
-
-
 class _ActorCritic(torch.autograd.Function):
     @staticmethod
     def forward(ctx, obs, mean, std, n_pol, *params):
@@ -47,30 +43,30 @@ class _ActorCritic(torch.autograd.Function):
         ctx.n_pol = n_pol
         ctx.has_norm = mean is not None
         if need:
-            ctx.save_for_backward(obs, *( [mean, std] if mean is not None else []), ppre, vpre, *params)
+            ctx.save_for_backward(obs, *([mean, std] if mean is not None else []), ppre, vpre, *params)
         return pol, val
 
     @staticmethod
     def backward(ctx, g_pol, g_val):
         saved = list(ctx.saved_tensors)
         obs = saved.pop(0)
-        if ctx.has_norm:
-            mean, std = saved.pop(0), saved.pop(0)
-            x = (obs - mean) / std
-        else:
-            x = obs
-        ppre, vpre = saved.pop(0), saved.pop(0)
-        params = saved
-        n_pol = ctx.n_pol
+        mean, std = (saved.pop(0), saved.pop(0)) if ctx.has_norm else (None, None)
+        ppre, vpre = saved[0], saved[1]
+        params, n_pol = saved[2:], ctx.n_pol
         grads = [None] * len(params)
 
         def net_backward(ws, pre, delta, base):
             for l in range(len(ws) - 1, -1, -1):
-                h_prev = x if l == 0 else torch.nn.functional.silu(pre[l - 1])
-                grads[base + 2 * l] = delta.t() @ h_prev
-                grads[base + 2 * l + 1] = delta.sum(0)
+                dsum = delta.sum(0)
+                if l == 0 and mean is not None:
+                    # dW_1 = delta' ((obs - mean) / std) = (delta' obs - (sum delta) mean') / std: the normalised observations
+                    # (114 MB at the learner's shape) are never materialised
+                    grads[base] = (delta.t() @ obs).addr_(dsum, mean, alpha=-1.0).div_(std)
+                else:
+                    grads[base + 2 * l] = delta.t() @ (obs if l == 0 else torch.nn.functional.silu(pre[l - 1]))
+                grads[base + 2 * l + 1] = dsum
                 if l > 0:
-                    delta = (delta @ ws[l]) * _dsilu(pre[l - 1])
+                    delta = torch.ops.aten.silu_backward(delta @ ws[l], pre[l - 1])      # (delta W_l) * silu'(z_{l-1}), one kernel
 
         if g_pol is not None:
             net_backward(params[0:2 * n_pol:2], ppre, g_pol.contiguous(), 0)

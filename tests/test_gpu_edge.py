@@ -183,6 +183,12 @@ def test_env_contact_and_pipeline_outputs():
     assert torch.isfinite(ps.contact_dist).all() and ps.xpos.shape == (4, 66, 3)
     assert torch.allclose(ps.contact_frame[:, :, 0], torch.tensor([0.0, 0.0, 1.0], device=DEV).expand(4, 59, 3))     # floor normal
     assert env.sys.contact_geom2[-5:].tolist() == [1, 62, 75, 89, 97] and env.sys.contact_link_idx[0].tolist() == [-1] * 59
+    c = env.contact(ps)                                   # brax State.contact, fields as in [NB mjcf.ipynb:917-921]
+    assert c.geom2.dtype == torch.int32 and c.geom2[-5:].tolist() == [1, 62, 75, 89, 97] and c.geom1.tolist() == [0] * 59
+    assert c.link_idx[1].tolist() == (env.sys.geom_bodyid[env.sys.contact_geom2] - 1).tolist()
+    assert c.friction.shape == (59, 5) and torch.allclose(c.friction[0], torch.tensor([1.5, 1.5, 0.005, 1e-4, 1e-4], device=DEV))
+    assert torch.allclose(c.solimp[0], torch.tensor([0.9, 0.95, 0.001, 0.5, 2.0], device=DEV)) and float(c.elasticity.abs().max()) == 0
+    assert c.dist is ps.contact_dist
     lean = envs.get_environment("rodent", track_pos=util.synthetic_track(), num_envs=4, xml_path="rodent_optimized.xml", iterations=8,
                                 ls_iterations=8, device=DEV)
     r2 = lean.reset(2)

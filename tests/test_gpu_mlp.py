@@ -112,8 +112,17 @@ def test_explicit_backward_matches_autograd():
     got = [p.grad.clone() for p in params]
     for p in params:
         p.grad = None
+    # the same accumulated into pre-allocated .grad buffers (train.py keeps them as views of the flat all-reduce buffer)
+    for p in params:
+        p.grad = torch.full_like(p, 0.5)
+    pol, val = fused_mlp.actor_critic(obs, mean, std, n.policy_network, n.value_network)
+    ((pol * gp).sum() + (val * gv).sum()).backward()
+    got_direct = [p.grad.clone() - 0.5 for p in params]
+    for p in params:
+        p.grad = None
     x = (obs - mean) / std
     (((n.policy_network(x)) * gp).sum() + (n.value_network(x).squeeze(-1) * gv).sum()).backward()
-    for p, a in zip(params, got):
+    for p, a, b in zip(params, got, got_direct):
         scale = max(p.grad.abs().max().item(), 1e-6)
         assert (a - p.grad).abs().max().item() <= 2e-4 * scale, (p.shape, (a - p.grad).abs().max().item(), scale)
+        assert (b - p.grad).abs().max().item() <= 2e-4 * scale + 1e-6, (p.shape, (b - p.grad).abs().max().item(), scale)

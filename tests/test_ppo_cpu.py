@@ -117,3 +117,44 @@ def test_data_parallel_two_ranks_gloo():
     np.testing.assert_allclose(p0, p1, rtol=0, atol=1e-7)
     np.testing.assert_allclose(m0, m1, rtol=0, atol=1e-7)
     assert c0 == c1 == 32 * 5 * 2 * 2                     # count sums the transitions of BOTH ranks
+
+
+def test_evaluator_matches_an_independent_restatement():
+    """`acting.Evaluator` [UP brax.training.acting.Evaluator; SURVEY.md a27] against a by-hand evaluation loop: same keys, same
+    (deterministic) policy, episode sums accumulate only while the episode is active, avg_episode_length counts active steps."""
+    from rodent_amd import jax_random
+    from rodent_amd.training import acting
+    torch.manual_seed(0)
+    nets = networks.make_ppo_networks(4, 2)
+    make_policy = networks.make_inference_fn(nets)
+    n, ep = 6, 30
+    key = jax_random.PRNGKey(11)
+    ev = acting.Evaluator(wrappers.wrap(PointEnv(n), episode_length=ep, action_repeat=1), lambda p: make_policy(p, deterministic=True), n, ep, 1, key)
+    got = ev.run_evaluation((None, nets.policy_network), training_metrics={"training/x": 1.0})
+    # restatement: plain env + explicit bookkeeping
+    _, unroll_key = jax_random.split(key)
+    env = PointEnv(n)
+    s = env.reset(jax_random.split(unroll_key, n))
+    pol = make_policy((None, nets.policy_network), deterministic=True)
+    active = torch.ones(n); rew = torch.zeros(n); dist = torch.zeros(n); steps = torch.zeros(n)
+    first = s
+    for t in range(ep):
+        a, _ = pol(s.obs, None)
+        s = env.step(s, a)
+        done = torch.maximum(s.done, torch.tensor(float(t + 1 >= ep)))
+        rew += s.reward * active; dist += s.metrics["dist"] * active; steps += active
+        active = active * (1 - done)
+    assert abs(got["eval/episode_reward"] - float(rew.mean())) < 1e-5
+    assert abs(got["eval/episode_dist"] - float(dist.mean())) < 1e-5
+    assert abs(got["eval/avg_episode_length"] - float(steps.mean())) < 1e-6
+    assert got["training/x"] == 1.0 and got["eval/sps"] > 0 and "eval/walltime" in got
+
+
+def test_training_state_is_carried():
+    out = ppo.train(environment=PointEnv(16), num_timesteps=16 * 5 * 2 * 3, episode_length=20, num_envs=16, batch_size=16,
+                    num_minibatches=2, unroll_length=5, num_updates_per_batch=2, num_evals=1, num_eval_envs=0,
+                    normalize_observations=True, seed=1, return_training_state=True)
+    ts = out[3]
+    assert ts.env_steps.dtype == torch.int32 and int(ts.env_steps) == 16 * 5 * 2 * 3
+    assert float(ts.normalizer_params.count) == 16 * 5 * 2 * 3
+    assert ts.params.policy is out[1][1] and len(ts.optimizer_state.state) > 0

@@ -11,10 +11,10 @@ echo "== phase profile"; timeout -k 10 120 python3 tools/phase_prof.py > $out/ph
 echo "== SQ"; bash tools/pmc_sq.sh gpurun_out/prof_$tag/sq > $out/sq.txt 2>&1; cat $out/sq.txt
 for f in 0 1; do
   cd /tmp
-  RR_FUSED_MLP=$f timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/ppo$f -o kt --output-format csv -- python3 $root/bench.py --config 3 --steps 1 --warmup 1 > $out/ppo$f.log 2>&1 || echo "ppo trace failed"
+  RR_FUSED_MLP=$f timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/ppo$f -o kt --output-format csv -- python3 $root/bench.py --config 3 --steps 1 --warmup 1 > $out/ppo$f.log 2>&1 || echo "ppo trace failed"
   cd $root
-  python3 tools/prof_summary.py $(find $out/ppo$f -name "*kernel_stats.csv" | head -n 1) $out/ppo_kernel_stats_fused$f.csv
-  echo "== PPO kernels, RR_FUSED_MLP=$f"; python3 - $out/ppo$f <<'PY'
+  python3 tools/prof_summary.py $(find /tmp/ppo$f -name "*kernel_stats.csv" | head -n 1) $out/ppo_kernel_stats_fused$f.csv
+  echo "== PPO kernels, RR_FUSED_MLP=$f"; python3 - /tmp/ppo$f <<'PY'
 import csv, glob, sys
 p = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(p)))
