@@ -20,7 +20,8 @@
 #define RR_LANES 64
 #define RR_DOFI 12   // ints per dof in k_dof_i
 #define RR_BODYI 12  // ints per body in k_body_i
-#define RR_RING 8    // rows of a level schedule in flight (ktables RING)
+#define RR_RING 8    // rows of a level schedule in flight (ktables RING); 12 / 16 measured 2-3 % slower in round 2
+
 #define RR_NPH 24    // phases of the diagnostic (s_memtime) build
 #define RR_MINVAL 1e-15f
 #define RR_MINIMP 0.0001f
@@ -313,7 +314,7 @@ template <int NBS, int NVS, int NCS, class DT>
 struct Wave {
   const DT& D;
   const RRTables& T;
-  const int lane;
+  int lane;               // re-derived (opaquely) at the head of every substep: see RR_FRAME_LOCAL in the kernel
   float* const lds;
   // LDS regions.  Aliases (liveness): s_crb == s_cinert (accumulated in place once cinert has been
   // consumed / written out), s_cacc|s_cfrc and the sin/cos scratch live in the region that later holds qLD,
@@ -1634,13 +1635,13 @@ template <int NBS, int NVS, int NCS, bool PROF, bool DBG, class DT>
 __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(const RRDims Dk, const RRTables T, const RRIO io_kernarg, const int num_envs,
                                                            const int n_frames) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int env = blockIdx.x;
+  int env = blockIdx.x;
   if (env >= num_envs) return;
   // the level schedules address LDS by absolute byte address: the dynamic segment must start at 0 (no static LDS here)
   if ((unsigned)(size_t)(float __attribute__((address_space(3)))*)lds != 0u) __builtin_trap();
   const DT D(Dk);
   Wave<NBS, NVS, NCS, DT> w(D, T, lds);
-  const int lane = threadIdx.x;
+  int lane = threadIdx.x;
   RRIO io = load_io();
   if (DBG) {   // the re-read block must be the real parameter, word for word; on a mismatch say so in the dump and touch nothing else
     const RRIO ref_io = io_kernarg;
@@ -1686,6 +1687,12 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
   int niter = 0;
   float xq1[4] = {1, 0, 0, 0};   // xquat of body 1 at the last forward pass (obs: xmat[1])
   for (int f = 0; f < frames; ++f) {
+    // RR_FRAME_LOCAL: everything derived from the lane id / env id (per-lane table addresses, output offsets) is loop-invariant,
+    // so the optimiser hoists it out of the substep loop and -- with 256 registers taken -- spills it to scratch at the loop head
+    // (45 dwords per lane in round 1's build, reloaded one by one inside every substep).  Re-deriving the two ids through an
+    // opaque copy per substep keeps those values local to their phase.
+    lane = opaque(lane); w.lane = lane;
+    asm volatile("" : "+s"(env));
     const bool last = f == frames - 1;
     if (last) io = load_io();
     float* dg = last ? dbg : nullptr;
@@ -1772,6 +1779,14 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
       for (int e = lane; e < 6 * D.nbody; e += RR_LANES) dg[D.g_cfrc + e] = w.s_cfrc[e];
     }
     w.contact_jobs();     // J*x jobs of the contacts in penetration: needed from here to the end of the substep
+    // WAVE PRIORITY.  2048 environments are exactly one resident round, so a launch lasts as long as its slowest environment,
+    // and an environment is slow when many contacts carry force (more J'f terms, more line-search rows).  The heavier of the two
+    // waves that share a SIMD issues first; the lighter one has slack.  Four graded levels (0 / 2+ / 6+ / 12+ contacts in
+    // penetration): -4.6 % launch time, bit-identical results (tools/variant_bench.py; a two-level split gave -3.1 %).
+    if (w.jnact >= 12) __builtin_amdgcn_s_setprio(3);          // (s_setprio takes an immediate)
+    else if (w.jnact >= 6) __builtin_amdgcn_s_setprio(2);
+    else if (w.jnact >= 2) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
     w.sync();
     for (int rep = 0; rep < RR_REP_MM; ++rep) w.mass_matrix();
     w.mass_matrix();
@@ -1820,6 +1835,8 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
   }
 
   w.template stamp<PROF>(14);
+  lane = opaque(lane); w.lane = lane;
+  asm volatile("" : "+s"(env));
   io = load_io();
   if (PROF && io.prof && lane == 0) for (int i = 0; i < RR_NPH; ++i) io.prof[(size_t)env * RR_NPH + i] = w.pt[i];
   // ---- write back state
@@ -1859,8 +1876,9 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
       const v3 v = ld3(io.track_pos + 3 * fi) - ld3(w.s_qpos);
       float m1[9];
       quat_to_mat(m1, xq1);
-      const float* xm = m1 + 3 * lane;
-      ob[o + lane] = xm[0] * v.x + xm[1] * v.y + xm[2] * v.z;
+      // row `lane` of xmat[1] by selects (indexing a register array by the lane id would put it into scratch memory)
+      const float r0 = m1[0] * v.x + m1[1] * v.y + m1[2] * v.z, r1 = m1[3] * v.x + m1[4] * v.y + m1[5] * v.z, r2 = m1[6] * v.x + m1[7] * v.y + m1[8] * v.z;
+      ob[o + lane] = lane == 0 ? r0 : (lane == 1 ? r1 : r2);
     }
     if (!is_reset) {
       float a2 = 0.0f;

@@ -1,7 +1,8 @@
 """Time several builds of librodent_hip.so on ONE in-contact start state with ONE action sequence (seeded), kernel hipEvent
 time, interleaved repeats; prints mean ms per 2048-env step and a checksum of the final state (pure scheduling / memory-
 instruction experiments must leave it bit-identical to the baseline).
-usage: variant_bench.py lib0.so lib1.so ...      (lib0 = baseline; the start state is generated with the in-tree build)"""
+usage: variant_bench.py lib0.so lib1.so[:assets_dir] ...      (lib0 = baseline; the start state is generated with the in-tree
+build; an optional assets directory after ':' gives that build its own model blobs, e.g. other schedule-table parameters)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -29,7 +30,9 @@ res = {l: [] for l in libs}
 sums = {}
 for rep in range(3):
     for l in libs:
-        out = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, RR_LIB=os.path.abspath(l))).decode().strip().split("\n")[-1].split()
+        lib, _, adir = l.partition(":")
+        env = dict(os.environ, RR_LIB=os.path.abspath(lib), **({"RR_ASSETS": os.path.abspath(adir)} if adir else {}))
+        out = subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip().split("\n")[-1].split()
         res[l].append(float(out[0])); sums[l] = out[1]
 base = min(res[libs[0]])
 for l in libs:
