@@ -208,7 +208,7 @@ def main():
             batch, nu = env._batch, env.action_size
 
             def one_step(state):
-                action = torch.rand(N, nu, device=dev, generator=gen) * 2 - 1
+                action = torch.empty(N, nu, device=dev).uniform_(-1.0, 1.0, generator=gen)      # fresh U(-1,1) draws, one launch
                 return wenv.step(state, action)
             workload = f"{model}.xml random-action rollout, Rodent.step through Episode(150)+AutoReset wrappers, CG 8/8, n_frames 10"
         else:
@@ -227,7 +227,7 @@ def main():
             first = {k: v.clone() for k, v in state.items()}
 
             def one_step(state):
-                ctrl = torch.rand(N, nu, device=dev, generator=gen) * 2 - 1
+                ctrl = torch.empty(N, nu, device=dev).uniform_(-1.0, 1.0, generator=gen)
                 out = {k: torch.empty_like(v) for k, v in state.items()}
                 batch.pipeline_step_to(state, out, ctrl, 10)
                 bad = (out["qpos"][:, 2] < 0.03) | (out["qpos"][:, 2] > 0.5) | ~torch.isfinite(out["qpos"]).all(1)   # keep the population in contact
