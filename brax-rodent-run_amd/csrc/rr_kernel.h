@@ -23,6 +23,9 @@
 #define RR_RING 8    // rows of a level schedule in flight (ktables RING); 12 / 16 measured 2-3 % slower in round 2
 
 #define RR_NPH 24    // phases of the diagnostic (s_memtime) build
+#ifndef RR_DPP_BLOCK
+#define RR_DPP_BLOCK 1     // one s_nop per row-broadcast stage instead of one per value (-0.6 % launch time, bit-identical)
+#endif
 #define RR_MINVAL 1e-15f
 #define RR_MINIMP 0.0001f
 #define RR_MAXIMP 0.9999f
@@ -208,12 +211,40 @@ __device__ __forceinline__ float wave_sum(float v) {
   v = dpp_add(v, 0); v = dpp_add(v, 1); v = dpp_add(v, 2); v = dpp_add(v, 3); v = dpp_add(v, 4); v = dpp_add(v, 5);
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+// the two row-broadcast steps of K >= 3 values as ONE asm block each: a single s_nop covers the VALU-write -> DPP-read hazard of
+// the first value, the K - 1 >= 2 instructions in between cover it for the others (dpp_add pays one s_nop per value)
+template <int K>
+__device__ __forceinline__ void dpp_bcast_stage(float* v) {
+  static_assert(K == 3 || K == 4 || K == 6, "instantiated widths");
+  if constexpr (K == 3)
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));
+  else if constexpr (K == 4)
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+  else
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_add_f32_dpp %5, %5, %5 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_bcast:31 row_mask:0xc bank_mask:0xf\n\tv_add_f32_dpp %5, %5, %5 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]));
+}
 template <int K>
 __device__ __forceinline__ void wave_sum_n(float* v) {
+  constexpr bool BLOCK = RR_DPP_BLOCK && (K == 3 || K == 4 || K == 6);
 #pragma unroll
-  for (int st = 0; st < 6; ++st)
+  for (int st = 0; st < (BLOCK ? 4 : 6); ++st)
 #pragma unroll
     for (int k = 0; k < K; ++k) v[k] = dpp_add(v[k], st);
+  if constexpr (BLOCK) dpp_bcast_stage<K>(v);
 #pragma unroll
   for (int k = 0; k < K; ++k) v[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[k]), 63));
 }
