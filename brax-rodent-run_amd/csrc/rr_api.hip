@@ -185,6 +185,8 @@ struct rr_batch {
   double total_ms = 0;
   int64_t launches = 0;
   unsigned long long* prof = nullptr;   // diagnostic phase-cycle buffer (rr_batch_set_profile)
+  const int32_t* env_map = nullptr;     // rr_batch_set_schedule
+  uint32_t* cost = nullptr;
 };
 
 template <typename Ptr>
@@ -313,6 +315,7 @@ static int launch(rr_batch* b, const rr_state* st, const float* ctrl, int n_fram
   kern_t kern = pick_kernel(b->m, b->prof != nullptr, io.dbg != nullptr || io.o_cdist || io.o_cpos || io.o_cframe);
   if (!kern) return fail(RR_EUNSUPPORTED, "launch: no diagnostic kernel instance for this model");
   io.prof = b->prof;
+  io.env_map = b->env_map; io.cost = b->cost;
   RRDims kd = b->kd;
   kd.iterations = b->m->kd.iterations; kd.ls_iterations = b->m->kd.ls_iterations;
   if (b->timing) {
@@ -489,6 +492,12 @@ extern "C" int rr_batch_set_profile(rr_batch* b, uint64_t* dev_cycles) {
     if (e != hipSuccess) return fail(RR_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
   }
   b->prof = (unsigned long long*)dev_cycles;
+  return RR_OK;
+}
+
+extern "C" int rr_batch_set_schedule(rr_batch* b, const int32_t* env_map, uint32_t* cost_cycles) {
+  if (!b) return fail(RR_EINVAL, "rr_batch_set_schedule: null batch");
+  b->env_map = env_map; b->cost = cost_cycles;
   return RR_OK;
 }
 

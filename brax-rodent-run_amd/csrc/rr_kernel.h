@@ -122,6 +122,8 @@ struct RRIO {
   float healthy_reward, ctrl_cost_weight, z_min, z_max;
   int terminate_when_unhealthy;
   unsigned long long* prof;  // diagnostic build only: [N][RR_NPH] cycle sums per phase
+  const int* env_map;        // nullable [N]: workgroup -> environment (SIMD pairing of heavy with light environments, rr_batch_set_schedule)
+  unsigned* cost;            // nullable [N]: shader cycles this launch spent on each environment
   int mode;  // 0 = forward only (pipeline_init), 1 = step; bit 1 (2) = env epilogue as reset (obs only)
 };
 
@@ -1674,6 +1676,11 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
   Wave<NBS, NVS, NCS, DT> w(D, T, lds);
   int lane = threadIdx.x;
   RRIO io = load_io();
+  const unsigned long long t_start = __builtin_readcyclecounter();
+  if (io.env_map) {          // a permutation of 0 .. num_envs-1 (host-checked length); environments are independent, so the mapping
+    env = __builtin_amdgcn_readfirstlane(io.env_map[env]);   // only decides which two of them share a SIMD
+    if ((unsigned)env >= (unsigned)num_envs) return;
+  }
   if (DBG) {   // the re-read block must be the real parameter, word for word; on a mismatch say so in the dump and touch nothing else
     const RRIO ref_io = io_kernarg;
     bool same = true;
@@ -1870,6 +1877,7 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
   asm volatile("" : "+s"(env));
   io = load_io();
   if (PROF && io.prof && lane == 0) for (int i = 0; i < RR_NPH; ++i) io.prof[(size_t)env * RR_NPH + i] = w.pt[i];
+  if (io.cost && lane == 0) io.cost[env] = (unsigned)(__builtin_readcyclecounter() - t_start);
   // ---- write back state
   for (int i = lane; i < D.nq; i += RR_LANES) io.qpos[(size_t)env * D.nq + i] = w.s_qpos[i];
   for (int i = lane; i < D.nv; i += RR_LANES) io.qvel[(size_t)env * D.nv + i] = w.s_qvel[i];

@@ -61,7 +61,8 @@ class Rodent(PipelineEnv):
                           healthy_z_range=healthy_z_range, reset_noise_scale=reset_noise_scale, solver=solver,
                           iterations=iterations, ls_iterations=ls_iterations, vision=vision, xml_path=xml_path,
                           n_frames=kwargs["n_frames"], pipeline_outputs=kwargs.get("pipeline_outputs", False),
-                          contact_outputs=kwargs.get("contact_outputs", False))
+                          contact_outputs=kwargs.get("contact_outputs", False), balance=kwargs.get("balance"),
+                          rebalance_every=kwargs.get("rebalance_every", 4))
 
     def with_num_envs(self, num_envs: int, device=None):
         """A sibling env with another batch size (ppo.train builds its per-rank and eval envs this way)."""
@@ -110,6 +111,7 @@ class Rodent(PipelineEnv):
         reward, done = torch.empty(N, device=dev), torch.empty(N, device=dev)
         metrics = torch.empty(N, 3, device=dev)
         action = action.to(dev, torch.float32).contiguous()
+        self._rebalance()
         self._batch.env_step_to(st_in, st, action, self._n_frames, self._env_io(cur_frame, obs, reward, done, metrics),
                                 state.info["cur_frame"], out)
         info = dict(state.info)

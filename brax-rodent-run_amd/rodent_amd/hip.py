@@ -44,7 +44,7 @@ class RREnvIO(C.Structure):
 
 EXPORTS = ["rr_model_load", "rr_model_dims", "rr_model_set_solver", "rr_model_destroy", "rr_model_table", "rr_kernarg_layout", "rr_batch_create",
            "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset", "rr_pipeline_step_to", "rr_env_step_to",
-           "rr_compute_gae", "rr_mlp_forward", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
+           "rr_compute_gae", "rr_mlp_forward", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_schedule", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
 
 _lib = None
 
@@ -83,6 +83,7 @@ def lib():
         L.rr_wrap_episode_autoreset.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32)] + \
             [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_void_p]
         L.rr_batch_set_profile.argtypes = [C.c_void_p, C.c_void_p]
+        L.rr_batch_set_schedule.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.rr_batch_set_timing.argtypes = [C.c_void_p, C.c_int32]
         L.rr_batch_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         _lib = L
@@ -242,6 +243,13 @@ class Batch:
     def set_profile(self, buf: Optional[torch.Tensor]):
         """Diagnostic: int64 device tensor [N,16] receiving per-phase cycle sums (None = off)."""
         _check(lib().rr_batch_set_profile(self.h, buf.data_ptr() if buf is not None else None))
+
+    def set_schedule(self, env_map: Optional[torch.Tensor], cost: Optional[torch.Tensor]):
+        """workgroup -> environment map (int32 [N] device, a permutation) and per-env cycle output (int32 [N] device); None = off.
+        The tensors must stay alive while the batch launches (C ABI `rr_batch_set_schedule`)."""
+        self._sched = (env_map, cost)
+        _check(lib().rr_batch_set_schedule(self.h, _ptr(env_map, torch.int32, self.N) if env_map is not None else None,
+                                           _ptr(cost, torch.int32, self.N) if cost is not None else None))
 
     def set_timing(self, enable: bool):
         _check(lib().rr_batch_set_timing(self.h, int(enable)))

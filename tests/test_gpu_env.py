@@ -133,3 +133,33 @@ def test_config5_rodent_pair_at_4096_envs():
     for k in st:
         assert torch.isfinite(s1[k]).all(), k
         assert torch.equal(s1[k], s2[k]) and torch.equal(s1[k][100:116], s3[k]), k
+
+
+def test_simd_pairing_schedule_is_result_neutral():
+    """`rr_batch_set_schedule` / `PipelineEnv._rebalance`: the workgroup -> environment map only decides which environments share
+    a SIMD.  A balanced env (re-paired every step here) and an unbalanced one produce bit-identical states, observations and
+    rewards over 12 steps; an explicit random map likewise; the per-env cycle counts come back non-zero."""
+    from rodent_amd import envs
+    N = 2048
+    mk = lambda **kw: envs.get_environment("rodent", track_pos=util.synthetic_track(), num_envs=N, xml_path="rodent_optimized.xml",
+                                           iterations=8, ls_iterations=8, device="cuda:0", **kw)
+    a, b = mk(balance=False), mk(balance=True, rebalance_every=1)
+    assert b._balance and not a._balance
+    sa, sb = a.reset(5), b.reset(5)
+    g = torch.Generator(device="cuda:0"); g.manual_seed(1)
+    for t in range(12):
+        act = torch.rand(N, a.action_size, device="cuda:0", generator=g) * 2 - 1
+        sa, sb = a.step(sa, act), b.step(sb, act)
+        assert torch.equal(sa.obs, sb.obs) and torch.equal(sa.reward, sb.reward) and torch.equal(sa.done, sb.done), t
+        assert torch.equal(sa.pipeline_state.qpos, sb.pipeline_state.qpos) and torch.equal(sa.info["cur_frame"], sb.info["cur_frame"])
+    assert int((b._cost > 0).sum()) == N
+    assert sorted(b._env_map.tolist()) == list(range(N)) and not torch.equal(b._env_map, torch.arange(N, dtype=torch.int32, device="cuda:0"))
+    # heavy with light: the two halves of the map hold the descending and the ascending end of the cost order
+    c = b._cost.cpu().numpy()
+    assert c[b._env_map[:N // 2].cpu().numpy()].mean() > c[b._env_map[N // 2:].cpu().numpy()].mean()
+    # an explicit random permutation through the ABI
+    perm = torch.randperm(N, device="cuda:0", generator=g).to(torch.int32)
+    a._batch.set_schedule(perm, None)
+    act = torch.rand(N, a.action_size, device="cuda:0", generator=g) * 2 - 1
+    sa2, sb2 = a.step(sa, act), b.step(sb, act)
+    assert torch.equal(sa2.obs, sb2.obs) and torch.equal(sa2.pipeline_state.qvel, sb2.pipeline_state.qvel)
