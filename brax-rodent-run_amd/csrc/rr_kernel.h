@@ -123,7 +123,7 @@ struct RRIO {
   int terminate_when_unhealthy;
   unsigned long long* prof;  // diagnostic build only: [N][RR_NPH] cycle sums per phase
   const int* env_map;        // nullable [N]: workgroup -> environment (SIMD pairing of heavy with light environments, rr_batch_set_schedule)
-  unsigned* cost;            // nullable [N]: shader cycles this launch spent on each environment
+  unsigned* cost;            // nullable [N]: work estimate of this launch per environment (line-search point evaluations x row blocks)
   int mode;  // 0 = forward only (pipeline_init), 1 = step; bit 1 (2) = env epilogue as reset (obs only)
 };
 
@@ -385,6 +385,7 @@ struct Wave {
   int con_nanc[NCS];
   float com0[3], com1[3];
   float gauss, cost, prev_cost;
+  int work;               // wave-uniform count of line-search point evaluations, weighted by row blocks: the scheduling cost estimate (rr_batch_set_schedule)
   unsigned long long pt_last, pt[RR_NPH];
   template <bool PROF> __device__ __forceinline__ void stamp(int i) {
     if (PROF) { const unsigned long long t = __builtin_readcyclecounter(); pt[i] += t - pt_last; pt_last = t; }
@@ -1495,7 +1496,9 @@ struct Wave {
     if (lo.d0 < p0.d0) { hi = p0; } else { hi = lo; lo = p0; }
     stamp<PROF>(18);
     bool swap = true;
+    work += 4 * (1 + (R > RR_LANES ? 1 : 0));          // the four evaluations outside the bracketing loop
     for (int it = 0; it < D.ls_iterations; ++it) {
+      work += 3 * (1 + (R > RR_LANES ? 1 : 0));        // the bracketing loop is what separates slow from fast environments
       bool done = !swap;
       done |= (lo.d0 < 0) && (lo.d0 > -gtol);
       done |= (hi.d0 > 0) && (hi.d0 < gtol);
@@ -1676,7 +1679,6 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
   Wave<NBS, NVS, NCS, DT> w(D, T, lds);
   int lane = threadIdx.x;
   RRIO io = load_io();
-  const unsigned long long t_start = __builtin_readcyclecounter();
   if (io.env_map) {          // a permutation of 0 .. num_envs-1 (host-checked length); environments are independent, so the mapping
     env = __builtin_amdgcn_readfirstlane(io.env_map[env]);   // only decides which two of them share a SIMD
     if ((unsigned)env >= (unsigned)num_envs) return;
@@ -1713,6 +1715,7 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
     }
     w.qacc[s] = w.Ma[s] = w.grad[s] = w.Mgrad[s] = w.search[s] = w.mv[s] = w.qfrc_con[s] = 0.0f;
   }
+  w.work = 0;
   for (int i = lane; i < D.nv; i += RR_LANES) w.s_arm[i] = T.dof_f[16 * i];
   if (lane < 6) w.s_cdof[6 * D.nv + lane] = 0.0f;
   if (lane == 0) w.s_qvel[D.nv] = 0.0f;
@@ -1877,7 +1880,7 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
   asm volatile("" : "+s"(env));
   io = load_io();
   if (PROF && io.prof && lane == 0) for (int i = 0; i < RR_NPH; ++i) io.prof[(size_t)env * RR_NPH + i] = w.pt[i];
-  if (io.cost && lane == 0) io.cost[env] = (unsigned)(__builtin_readcyclecounter() - t_start);
+  if (io.cost && lane == 0) io.cost[env] = (unsigned)w.work;
   // ---- write back state
   for (int i = lane; i < D.nq; i += RR_LANES) io.qpos[(size_t)env * D.nq + i] = w.s_qpos[i];
   for (int i = lane; i < D.nv; i += RR_LANES) io.qvel[(size_t)env * D.nv + i] = w.s_qvel[i];

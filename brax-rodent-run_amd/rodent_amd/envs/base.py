@@ -120,14 +120,14 @@ class PipelineEnv:
         self.num_envs = int(num_envs)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._batch = hip.Batch(sys.model, self.num_envs, self.device)
-        # SIMD pairing (scheduling only; results are unaffected): when the batch is exactly one resident round of the GPU
-        # (2 waves per SIMD: N = 8 x CUs), workgroups w and w + N/2 share a SIMD and the launch lasts as long as its slowest
-        # environment.  Every `rebalance_every` steps the envs are re-mapped so that the costliest ones of the last launch
-        # (cycles reported by the kernel) sit with the cheapest ones.  Measured on MI355X: heavy|light pairs 1.412 ms,
-        # random 1.452 ms, heavy|heavy 1.519 ms for the same 2048 states (tools/pairing_probe.py).
-        cus = torch.cuda.get_device_properties(self.device).multi_processor_count if self.device.type == "cuda" else 0
-        import os
-        self._balance = ((self.num_envs == 8 * cus) and os.environ.get("RR_BALANCE", "1") == "1") if balance is None else bool(balance)
+        # SIMD pairing (scheduling only; results are unaffected; OFF by default).  When the batch is exactly one resident round of
+        # the GPU (2 waves per SIMD: N = 8 x CUs), workgroups w and w + N/2 share a SIMD and the launch lasts as long as its
+        # slowest environment.  With `balance=True` the envs are re-mapped every `rebalance_every` steps so that the costliest
+        # ones of the last launch (work estimate reported by the kernel) sit with the cheapest ones.  With the TRUE cost of the
+        # step being launched the effect is real (MI355X, same 2048 states: heavy|light pairs 1.412 ms, random 1.452 ms,
+        # heavy|heavy 1.519 ms; tools/pairing_probe.py), but the previous step's cost does not predict it well enough under
+        # random actions: the bench measured 1.5027 ms balanced against 1.5038 ms unbalanced, so it stays an option.
+        self._balance = bool(balance)
         self._rebalance_every, self._launches = max(1, int(rebalance_every)), 0
         if self._balance:
             self._env_map = torch.arange(self.num_envs, dtype=torch.int32, device=self.device)

@@ -163,7 +163,8 @@ int rr_wrap_episode_autoreset(int32_t num_envs, int32_t narr, const float* const
 
 /* Scheduling of the environments on the GPU (results are unaffected: environments are independent).  `env_map` (device,
  * [N] int32, a permutation of 0..N-1, or NULL = identity): workgroup w steps environment env_map[w]; `cost_cycles` (device,
- * [N] uint32, or NULL): every launch writes the shader cycles it spent on environment e to cost_cycles[e].  With N equal to
+ * [N] uint32, or NULL): every launch writes a work estimate of environment e (line-search point evaluations, the quantity
+ * that separates slow from fast environments; NOT cycles, which depend on the SIMD neighbour) to cost_cycles[e].  With N equal to
  * one resident round (2 waves per SIMD: N = 8 x number of CUs) workgroups w and w + N/2 share a SIMD, and a launch lasts as
  * long as its slowest environment: pairing the costliest environments of the previous step with the cheapest ones shortens
  * it (rodent_amd/envs/base.py: PipelineEnv._rebalance).  Both pointers are read at every later launch of this batch. */
