@@ -58,6 +58,7 @@ class Model:
         self.impratio = float(t["opt_impratio"]); self.meaninertia = float(t["stat_meaninertia"])
         self.iterations = int(t["opt_iterations"]) if iterations is None else iterations
         self.ls_iterations = int(t["opt_ls_iterations"]) if ls_iterations is None else ls_iterations
+        self.solver = "cg"          # or "newton" [REF Rodent_Env_Brax.py:42-45]
         nb, nv = self.nbody, self.nv
         # dof d moves body b  <=>  body(d) is b or an ancestor of b
         par = t["body_parentid"]
@@ -346,7 +347,12 @@ def solve(m: Model, d: Data):
 
     def update_gradient(c):
         c.grad = c.Ma - d.qfrc_smooth - c.qfrc_constraint
-        c.Mgrad = cho_solve(d.Mchol, c.grad)
+        if m.solver == "newton":        # H = M + J' diag(D active) J  [UP mjx solver._update_gradient]
+            act = c.Jaref < 0
+            H = M + (J[act].T * Dv[act]) @ J[act]
+            c.Mgrad = cho_solve(cho_factor(H), c.grad)
+        else:
+            c.Mgrad = cho_solve(d.Mchol, c.grad)
 
     def create(qacc, grad=True):
         c = Ctx()
@@ -414,7 +420,7 @@ def solve(m: Model, d: Data):
         pg, pM = c.grad.copy(), c.Mgrad.copy()
         update_constraint(c)
         update_gradient(c)
-        beta = max(0.0, c.grad @ (c.Mgrad - pM) / max(MINVAL, pg @ pM))
+        beta = 0.0 if m.solver == "newton" else max(0.0, c.grad @ (c.Mgrad - pM) / max(MINVAL, pg @ pM))
         c.search = -c.Mgrad + beta * c.search
         niter += 1
     d.qacc, d.qfrc_constraint, d.efc_force, d.solver_niter = c.qacc, c.qfrc_constraint, c.force, niter

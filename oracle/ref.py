@@ -30,6 +30,7 @@ def _lib(precision: str):
         lib.ref_model_dim.restype = C.c_int
         lib.ref_model_dim.argtypes = [C.c_void_p, C.c_char_p]
         lib.ref_model_set_iterations.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        lib.ref_model_set_solver.argtypes = [C.c_void_p, C.c_int]
         lib.ref_data_new.restype = C.c_void_p
         lib.ref_data_new.argtypes = [C.c_void_p]
         lib.ref_data_free.argtypes = [C.c_void_p]
@@ -65,6 +66,10 @@ class RefModel:
             raise RuntimeError(f"oracle: cannot load model blob {blob_path}")
         for k in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nM", "ncon", "nlimit", "nefc", "obs_dim"):
             setattr(self, k, self.lib.ref_model_dim(self.h, k.encode()))
+
+    def set_solver(self, solver: str):
+        """'cg' or 'newton' [REF Rodent_Env_Brax.py:42-45]"""
+        self.lib.ref_model_set_solver(self.h, {"cg": 1, "newton": 2}[solver.lower()])
 
     def set_iterations(self, iterations, ls_iterations):
         self.lib.ref_model_set_iterations(self.h, iterations, ls_iterations)

@@ -65,7 +65,7 @@ typedef struct ref_model {
   unsigned char* raw;
   /* dims */
   int nq, nv, nu, na, nbody, njnt, ngeom, nM, ncon, nlimit, nefc, obs_dim;
-  int iterations, ls_iterations;
+  int iterations, ls_iterations, solver; /* solver: 1 = CG, 2 = Newton (mjtSolver) */
   real timestep, gravity[3], tolerance, ls_tolerance, impratio, meaninertia;
   /* int tables (borrowed from blob) */
   const int32_t *body_parentid, *body_rootid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum, *body_lastdof;
@@ -135,6 +135,7 @@ ref_model* ref_model_load(const char* path) {
   m->nM = iscalar(m, "nM"); m->ncon = iscalar(m, "ncon"); m->nlimit = iscalar(m, "nlimit");
   m->nefc = iscalar(m, "nefc"); m->obs_dim = iscalar(m, "obs_dim");
   m->iterations = iscalar(m, "opt_iterations"); m->ls_iterations = iscalar(m, "opt_ls_iterations");
+  m->solver = iscalar(m, "opt_solver");
   real* t;
   t = rtab(m, "opt_timestep"); m->timestep = t[0]; free(t);
   t = rtab(m, "opt_gravity"); memcpy(m->gravity, t, 3 * sizeof(real)); free(t);
@@ -166,6 +167,7 @@ ref_model* ref_model_load(const char* path) {
   return m;
 }
 
+void ref_model_set_solver(ref_model* m, int solver) { m->solver = solver; }  /* 1 = CG, 2 = Newton */
 void ref_model_set_iterations(ref_model* m, int iterations, int ls_iterations) {
   m->iterations = iterations; m->ls_iterations = ls_iterations;
 }
@@ -741,12 +743,51 @@ static void update_constraint(const ref_model* m, ref_data* d, ctx_scalars* s) {
   s->gauss = gauss;
   s->cost = R(0.5) * cost + gauss;
 }
+/* Newton direction [UP mjx solver._update_gradient, SolverType.NEWTON; REF Rodent_Env_Brax.py:42-45 accepts solver='newton']:
+ * H = M + J' diag(D * active) J (dense), Cholesky, Mgrad = H^-1 grad */
+static void newton_direction(const ref_model* m, ref_data* d) {
+  int nv = m->nv;
+  real* H = (real*)calloc((size_t)nv * nv, sizeof(real));
+  for (int i = 0; i < nv; i++) {                          /* full_m: the sparse mass matrix as a dense symmetric one */
+    int a = m->dof_Madr[i], j = i;
+    while (j >= 0) { H[i * nv + j] = H[j * nv + i] = d->qM[a++]; j = m->dof_parentid[j]; }
+  }
+  for (int r = 0; r < m->nefc; r++) {
+    if (!(d->Jaref[r] < 0)) continue;
+    const real* J = d->efc_J + (size_t)r * nv;
+    for (int i = 0; i < nv; i++) {
+      if (J[i] == 0) continue;
+      real di = d->efc_D[r] * J[i];
+      for (int j = 0; j < nv; j++) H[i * nv + j] += di * J[j];
+    }
+  }
+  for (int k = 0; k < nv; k++) {                          /* H = L L', lower triangle in place */
+    real p = SQRT(H[k * nv + k]);
+    H[k * nv + k] = p;
+    for (int i = k + 1; i < nv; i++) H[i * nv + k] /= p;
+    for (int i = k + 1; i < nv; i++)
+      for (int j = k + 1; j <= i; j++) H[i * nv + j] -= H[i * nv + k] * H[j * nv + k];
+  }
+  real* x = d->Mgrad;
+  for (int i = 0; i < nv; i++) {
+    real s = d->grad[i];
+    for (int j = 0; j < i; j++) s -= H[i * nv + j] * x[j];
+    x[i] = s / H[i * nv + i];
+  }
+  for (int i = nv - 1; i >= 0; i--) {
+    real s = x[i];
+    for (int j = i + 1; j < nv; j++) s -= H[j * nv + i] * x[j];
+    x[i] = s / H[i * nv + i];
+  }
+  free(H);
+}
 static void update_gradient(const ref_model* m, ref_data* d) {
   for (int i = 0; i < m->nv; i++) {
     d->grad[i] = d->Ma[i] - d->qfrc_smooth[i] - d->qfrc_constraint[i];
     d->Mgrad[i] = d->grad[i];
   }
-  solve_ld(m, d->qLD, d->qLDiagInv, d->Mgrad);
+  if (m->solver == 2) newton_direction(m, d);
+  else solve_ld(m, d->qLD, d->qLDiagInv, d->Mgrad);
 }
 static void ctx_create(const ref_model* m, ref_data* d, ctx_scalars* s, int grad) {
   int nv = m->nv;
@@ -850,6 +891,7 @@ static void solve(const ref_model* m, ref_data* d) {
     for (int i = 0; i < nv; i++) beta += d->grad[i] * (d->Mgrad[i] - prev_Mgrad[i]);
     beta = beta / FMAX(MINVAL, gg_prev);
     beta = FMAX(0, beta);
+    if (m->solver == 2) beta = 0;            /* Newton: search = -Mgrad */
     for (int i = 0; i < nv; i++) d->search[i] = -d->Mgrad[i] + beta * d->search[i];
     niter++;
   }

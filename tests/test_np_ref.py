@@ -128,3 +128,30 @@ def test_c_oracle_reproduces_the_np_ref_fixtures(oracle_built, model_name):
                 assert np.abs(c.get("qpos") - g[f"env_{tag}_qpos"][e]).max() < 1e-8
                 assert _rel(obs, g[f"env_{tag}_obs"][e]) < 1e-7
                 assert abs(rew - g[f"env_{tag}_reward"][e, 0]) < 1e-8
+
+
+def test_newton_solver_in_both_formulations(oracle_built):
+    """`solver='newton'` [REF Rodent_Env_Brax.py:42-45; UP mjx solver, SolverType.NEWTON: H = M + J' diag(D active) J, Cholesky,
+    search = -H^-1 grad]: the C oracle (dense Cholesky by hand) and np_ref (scipy) agree to double round-off with identical
+    iteration counts, and Newton reaches the optimum a long CG run converges to."""
+    ref = oracle_built
+    from rodent_amd import assets
+    st, M, tab = util.settled_states(ref, "rodent_optimized", 4, seed=3, iterations=(8, 8))
+    M.set_solver("newton")
+    m = np_ref.Model(tab, 8, 8)
+    m.solver = "newton"
+    rng = np.random.default_rng(0)
+    for e in range(4):
+        ctrl = rng.uniform(-1, 1, M.nu)
+        c = util.oracle_forward(ref, M, st, e, ctrl)
+        d = _np_data(m, st, e, ctrl)
+        np_ref.forward(m, d)
+        assert d.solver_niter == int(c.get("solver_niter")[0]) <= 8
+        assert _rel(d.qacc, c.get("qacc")) < 1e-10
+    Mcg = ref.RefModel(assets.asset_path("rodent_optimized"), "f64")
+    Mcg.set_iterations(300, 50)
+    M.set_iterations(20, 50)
+    for e in range(2):
+        a, b = util.oracle_forward(ref, M, st, e, np.zeros(M.nu)), util.oracle_forward(ref, Mcg, st, e, np.zeros(M.nu))
+        assert abs(a.get("solver_cost")[0] - b.get("solver_cost")[0]) <= 1e-8 * abs(b.get("solver_cost")[0])
+        assert _rel(a.get("qacc"), b.get("qacc")) < 1e-4 and a.get("solver_niter")[0] < 10 < b.get("solver_niter")[0]
