@@ -34,6 +34,7 @@ struct rr_model {
   std::vector<const char*> dbg_cnames;
   int NBS, NVS, NCS;
   bool stage_ok = true;
+  int solver = 1;          // 1 = CG, 2 = Newton [REF Rodent_Env_Brax.py:42-45]
 
   const Entry* find(const char* n) const { auto it = e.find(n); return it == e.end() ? nullptr : &it->second; }
   int iscalar(const char* n) const { const Entry* x = find(n); return x ? ((const int32_t*)x->data)[0] : 0; }
@@ -43,7 +44,9 @@ struct rr_model {
 static void layout(rr_model* m) {
   RRDims& k = m->kd;
   const rr_dims& d = m->dims;
-  const RRLayout L = rr_layout(d.nq, d.nv, d.nu, d.nbody, d.nM, d.ncon);
+  const RRLayout L = rr_layout(d.nq, d.nv, d.nu, d.nbody, d.nM, d.ncon, m->solver == 2);
+  k.o_H = L.o_H; k.o_Mp = L.o_Mp; k.o_anc = L.o_anc; k.solver = m->solver;
+  m->dbg_names.clear(); m->dbg_off.clear(); m->dbg_size.clear(); m->dbg_cnames.clear();      // layout() may run again (rr_model_set_solver_type)
   k.o_qpos = L.o_qpos; k.o_qvel = L.o_qvel; k.o_act = L.o_act; k.o_ctrl = L.o_ctrl; k.o_xpos = L.o_xpos; k.o_xquat = L.o_xquat;
   k.o_cinert = L.o_cinert; k.o_cdof = L.o_cdof; k.o_cvel = L.o_cvel; k.o_qLD = L.o_qLD; k.o_vec = L.o_vec; k.o_x = L.o_x;
   k.o_arm = L.o_arm; k.o_warm = L.o_warm; k.o_qact = L.o_qact; k.o_jlist = L.o_jlist; k.lds_floats = L.lds_floats;
@@ -67,6 +70,7 @@ static void layout(rr_model* m) {
   for (auto& s : m->dbg_names) m->dbg_cnames.push_back(s.c_str());
   m->dims.lds_bytes = o * (int)sizeof(float);
   m->dims.dbg_floats = g;
+  m->dims.solver = m->solver;
 }
 
 extern "C" int rr_model_load(const char* path, rr_model** out) {
@@ -154,6 +158,16 @@ extern "C" int rr_model_set_solver(rr_model* m, int32_t it, int32_t ls) {
   m->dims.ls_iterations = m->kd.ls_iterations = ls;
   return RR_OK;
 }
+extern "C" int rr_model_set_solver_type(rr_model* m, int32_t solver) {
+  if (!m || (solver != 1 && solver != 2)) return fail(RR_EINVAL, "rr_model_set_solver_type: solver must be 1 (cg) or 2 (newton)");
+  if (solver == 2 && !(m->NBS == 2 && m->NVS == 2 && m->NCS == 1))
+    return fail(RR_EUNSUPPORTED, "rr_model_set_solver_type: the Newton instance exists for the single-rodent models only");
+  if (solver == 2 && 4 * ((m->dims.nv + 3) & ~3) > std::max(7 * m->dims.nbody + 4, 6 * m->dims.nv))
+    return fail(RR_EUNSUPPORTED, "rr_model_set_solver_type: the four Hessian rows do not fit the pose cells");
+  m->solver = solver;
+  layout(m);
+  return RR_OK;
+}
 extern "C" void rr_model_destroy(rr_model* m) { delete m; }
 extern "C" int rr_model_table(const rr_model* m, const char* name, const void** host_ptr, size_t* count, int32_t* dtype) {
   if (!m || !name || !host_ptr) return fail(RR_EINVAL, "rr_model_table: null argument");
@@ -226,7 +240,9 @@ typedef void (*kern_t)(const RRDims, const RRTables, const RRIO, const int, cons
 // launch when rr_outputs.debug is given), cycle-stamp profile (diagnostic, rodent dims or generic 2,2,1).
 static kern_t pick_kernel(const rr_model* m, bool prof = false, bool dbg = false) {
   const int nbs = m->NBS, nvs = m->NVS, ncs = m->NCS;
-  if (prof) return (nbs == 2 && nvs == 2 && ncs == 1) ? (RRDimsRodent::matches(m->kd) ? rr_step_kernel<2, 2, 1, true, false, RRDimsRodent> : rr_step_kernel<2, 2, 1, true, false, RRDims>) : nullptr;
+  if (prof && m->solver != 2) return (nbs == 2 && nvs == 2 && ncs == 1) ? (RRDimsRodent::matches(m->kd) ? rr_step_kernel<2, 2, 1, true, false, RRDimsRodent> : rr_step_kernel<2, 2, 1, true, false, RRDims>) : nullptr;
+  if (m->solver == 2)     // Newton: the (2,2,1) generic instances only (rr_model_set_solver_type checks)
+    return prof ? nullptr : (dbg ? rr_step_kernel<2, 2, 1, false, true, RRDims, true> : rr_step_kernel<2, 2, 1, false, false, RRDims, true>);
   if (dbg) {
     if (nbs == 1 && nvs == 1 && ncs == 1) return rr_step_kernel<1, 1, 1, false, true, RRDims>;
     if (nbs == 2 && nvs == 2 && ncs == 1) return rr_step_kernel<2, 2, 1, false, true, RRDims>;
@@ -254,6 +270,22 @@ extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t devi
   UP(act_f, "k_act_f") UP(con_f, "k_con_f") UP(root_mass, "k_root_mass")
 #undef UP
   if ((rc = upload_levels(b, "k_factor3", &b->T.factor3)) || (rc = upload_levels(b, "k_linv", &b->T.linv))) { rr_batch_destroy(b); return rc; }
+  {   // ancestor ids along the rows of M (Newton): byte Madr[i] + p = the p-th ancestor of dof i (p = 0: i itself)
+    const Entry *an = m->find("dof_anc"), *ad = m->find("dof_ancadr"), *ma = m->find("dof_Madr");
+    std::vector<unsigned char> bytes(((size_t)m->dims.nM + 3) / 4 * 4 + 4, 0);
+    if (an && ad && ma) {
+      const int32_t *anc = (const int32_t*)an->data, *adr = (const int32_t*)ad->data, *madr = (const int32_t*)ma->data;
+      for (int i = 0; i < m->dims.nv; ++i) {
+        const int n = adr[i + 1] - adr[i];                 // chain root .. self
+        for (int p = 0; p < n; ++p) bytes[madr[i] + p] = (unsigned char)anc[adr[i] + n - 1 - p];
+      }
+    } else if (m->solver == 2) { rr_batch_destroy(b); return fail(RR_EIO, "rr_batch_create: blob lacks the ancestor tables the Newton solver needs"); }
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, bytes.size()));
+    b->dev_allocs.push_back(p);
+    HIPCHK(hipMemcpy(p, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+    b->T.anc4 = (rr_gi)p;
+  }
   kern_t kern = pick_kernel(m);
   if (!m->stage_ok) { rr_batch_destroy(b); return fail(RR_EUNSUPPORTED, "rr_batch_create: 4*ncon + nv exceeds the line-search staging cells (6*nbody)"); }
   if (m->dims.lds_bytes > 64 * 1024) { rr_batch_destroy(b); return fail(RR_EUNSUPPORTED, "rr_batch_create: per-env working set exceeds the 64 KiB of LDS one workgroup may address"); }

@@ -37,6 +37,8 @@ struct RRDims {
   // LDS offsets (floats)
   int o_qpos, o_qvel, o_act, o_ctrl, o_xpos, o_xquat, o_cinert, o_cdof, o_cvel,
       o_qLD, o_vec, o_x, o_arm, o_warm, o_qact, o_jlist, lds_floats;
+  // Newton instance only (solver == 2): pair arrays of the Hessian and of a copy of M, ancestor-id bytes; 0 otherwise
+  int o_H, o_Mp, o_anc, solver;
   // debug dump offsets (floats)
   int g_xpos, g_xquat, g_xmat, g_com, g_cinert, g_crb, g_cdof, g_cvel, g_cfrc, g_qM, g_qLD, g_dinv, g_bias, g_passive,
       g_actuator, g_smooth, g_qacc_smooth, g_con_dist, g_con_pos, g_con_frame, g_con_D, g_con_aref, g_lim, g_qacc,
@@ -47,10 +49,11 @@ struct RRDims {
 // kernel instance compiled for fixed model dimensions.
 struct RRLayout {
   int o_qpos, o_qvel, o_act, o_ctrl, o_xpos, o_xquat, o_cinert, o_cdof, o_cvel, o_qLD, o_vec, o_x, o_arm, o_warm, o_qact, o_jlist, lds_floats;
+  int o_H, o_Mp, o_anc;
 };
 constexpr int rr_imax(int a, int b) { return a > b ? a : b; }
 constexpr int rr_up4(int n) { return (n + 3) & ~3; }
-constexpr RRLayout rr_layout(int nq, int nv, int nu, int nbody, int nM, int ncon) {
+constexpr RRLayout rr_layout(int nq, int nv, int nu, int nbody, int nM, int ncon, bool newton = false) {
   RRLayout k{};
   int o = 0;
   k.o_qpos = o; o += rr_up4(nq);
@@ -73,6 +76,12 @@ constexpr RRLayout rr_layout(int nq, int nv, int nu, int nbody, int nM, int ncon
   k.o_warm = o; o += rr_up4(nv);
   k.o_qact = o; o += rr_up4(nv);
   k.o_jlist = o; o += rr_up4(ncon);      // ids of the contacts in penetration, by rank (J*x jobs)
+  if (newton) {   // Newton solver: the Hessian H = M + J'DJ has M's tree sparsity (every constraint row lives on ONE ancestor chain),
+                  // so it is held, factorised and inverted exactly like M: a second pair array; plus M itself (for M*search)
+    k.o_H = o; o += rr_up4(rr_imax(rr_imax(2 * (nM + 20), 12 * nbody), 2 * nv));
+    k.o_Mp = o; o += rr_up4(rr_imax(rr_imax(2 * (nM + 20), 12 * nbody), 2 * nv));
+    k.o_anc = o; o += rr_up4((nM + 3) / 4 + 1);       // p-th ancestor of dof i at byte Madr[i] + p
+  }
   k.lds_floats = o;
   return k;
 }
@@ -103,7 +112,7 @@ struct RRDimsRodent : RRDims {
 typedef const int __attribute__((address_space(1)))* rr_gi;
 typedef const float __attribute__((address_space(1)))* rr_gf;
 struct RRTables {
-  rr_gi factor3, linv, coljob, rowjob, jobown, body_i, jnt_i, dof_i, M_ij_k, body_anc, con_chain_rows, con_i;
+  rr_gi factor3, linv, coljob, rowjob, jobown, body_i, jnt_i, dof_i, M_ij_k, body_anc, con_chain_rows, con_i, anc4;
   rr_gf body_f, jnt_f, dof_f, act_f, con_f, root_mass;
 };
 
@@ -343,7 +352,7 @@ __device__ __forceinline__ BodyC load_bodyc(const RRTables& T, int b, int nbody)
 #define RR_REP_KIN 0
 #endif
 typedef float rr_f2 __attribute__((ext_vector_type(2)));
-template <int NBS, int NVS, int NCS, class DT>
+template <int NBS, int NVS, int NCS, class DT, bool NEWTON = false>
 struct Wave {
   const DT& D;
   const RRTables& T;
@@ -354,6 +363,9 @@ struct Wave {
   // s_buf reuses xpos|xquat after the contact geometry has been taken.
   float *s_qpos, *s_qvel, *s_act, *s_ctrl, *s_xpos, *s_xquat, *s_cinert, *s_crb, *s_cdof, *s_cvel, *s_cacc,
       *s_cfrc, *s_buf, *s_sc, *s_qLD, *s_vec, *s_x, *s_arm, *s_warm, *s_qact;
+  float *s_H, *s_Mp;      // Newton instance: Hessian pairs, copy of the M pairs
+  unsigned char* s_anc;   // Newton instance: ancestor ids along the rows of M
+  float dinvH[NVS];       // Newton instance: 1/D of the Hessian's factor
   int* s_jlist;           // contact ids by rank (J*x jobs)
 
   static constexpr int W = NVS * RR_LANES;
@@ -399,6 +411,7 @@ struct Wave {
     s_cacc = s_qLD; s_cfrc = s_qLD + 6 * d.nbody; s_sc = s_qLD; s_buf = s_xpos;
     s_vec = l + d.o_vec; s_x = l + d.o_x; s_arm = l + d.o_arm; s_warm = l + d.o_warm; s_qact = l + d.o_qact;
     s_jlist = (int*)(l + d.o_jlist);
+    s_H = l + d.o_H; s_Mp = l + d.o_Mp; s_anc = (unsigned char*)(l + d.o_anc);
   }
 
   // One wavefront owns the environment: its LDS instructions execute in program order, so a
@@ -843,8 +856,9 @@ struct Wave {
   typedef rr_f2 __attribute__((address_space(3)))* rr_lf2;
   static __device__ __forceinline__ rr_f2 lds_ld2(int byte_adr) { return *(rr_lf2)(size_t)(unsigned)byte_adr; }
   static __device__ __forceinline__ void lds_st2(int byte_adr, rr_f2 v) { *(rr_lf2)(size_t)(unsigned)byte_adr = v; }
-  template <bool DIV>
-  __device__ __forceinline__ void run_levels(rr_gi table, int nrows) {
+  // SHIFT: the schedules' LDS addresses are baked for the pair array at o_qLD; `delta` (bytes) moves them to another pair array
+  template <bool DIV, bool SHIFT = false>
+  __device__ __forceinline__ void run_levels(rr_gi table, int nrows, int delta = 0) {
     typedef const rr_v4i __attribute__((address_space(1)))* rr_gv4;
     rr_gv4 tab = (rr_gv4)table;
     rr_v4i ring[RR_RING];
@@ -856,8 +870,9 @@ struct Wave {
       for (int u = 0; u < RR_RING; ++u) {
         const rr_v4i e = ring[u];
         ring[u] = tab[(r0 + RR_RING + u) * RR_LANES + lane];
-        const int a8 = e.x & 0xFFFF, b8 = (int)((unsigned)e.x >> 16);
-        const int d8[4] = {e.y & 0xFFFF, (int)((unsigned)e.y >> 16), e.z & 0xFFFF, (int)((unsigned)e.z >> 16)};
+        const int sh = SHIFT ? delta : 0;
+        const int a8 = (e.x & 0xFFFF) + sh, b8 = (int)((unsigned)e.x >> 16) + sh;
+        const int d8[4] = {(e.y & 0xFFFF) + sh, (int)((unsigned)e.y >> 16) + sh, (e.z & 0xFFFF) + sh, (int)((unsigned)e.z >> 16) + sh};
         const rr_f2 va = lds_ld2(a8);
         rr_f2 vp = {1.0f, 1.0f};
         if (DIV) vp = lds_ld2(a8 - (e.w & 0xFFFF) + 8);
@@ -988,8 +1003,10 @@ struct Wave {
   }
   // DAMPED = true: the factor of M + dt*diag(damping) (second half of the pairs, dinvB)
   template <bool DAMPED = false>
-  __device__ __forceinline__ void ldl_solve(float* x) {
-    const float* mat = s_qLD + (DAMPED ? 1 : 0);       // half of the pairs
+  __device__ __forceinline__ void ldl_solve(float* x) { ldl_solve_on<DAMPED>(x, s_qLD + (DAMPED ? 1 : 0), DAMPED ? dinvB : dinv); }
+  // mat: one half of a pair array holding an inverse factor; di: its 1/D
+  template <bool DAMPED = false>
+  __device__ __forceinline__ void ldl_solve_on(float* x, const float* mat, const float* di) {
     Jobs jb;
     load_jobs(jb);
 #pragma unroll
@@ -1001,7 +1018,7 @@ struct Wave {
     float y[NVS];
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
-      y[s] = (x[s] - merge_pieces(s_buf, jb.own[s] & 255, (jb.own[s] >> 8) & 255, D.cmax)) * (DAMPED ? dinvB[s] : dinv[s]);
+      y[s] = (x[s] - merge_pieces(s_buf, jb.own[s] & 255, (jb.own[s] >> 8) & 255, D.cmax)) * di[s];
     }
     // every lane has taken its column pieces of x (hand-off above): the vector cells can take y
 #pragma unroll
@@ -1020,14 +1037,15 @@ struct Wave {
   // y = M * s_vec (s_vec must be visible).  Row i of the symmetric product is its ancestor part (entries of row i) plus
   // its descendant part (entries (k, i) of the rows below): the two sparse products of ldl_solve on the same vector, with
   // the same balanced jobs (k_coljob / k_rowjob), on the first half of the pairs while it still holds M.  No atomics.
-  __device__ __forceinline__ void mul_m(float* y) {
+  __device__ __forceinline__ void mul_m(float* y) { mul_m_on(y, s_qLD); }
+  __device__ __forceinline__ void mul_m_on(float* y, const float* mp) {
     constexpr int WJ = NJS * RR_LANES;
     Jobs jb;
     load_jobs(jb);
 #pragma unroll
     for (int s = 0; s < NJS; ++s) {
-      s_buf[s * RR_LANES + lane] = col_piece(jb, s, s_qLD, s_vec);
-      s_buf[WJ + s * RR_LANES + lane] = row_piece(jb, s, s_qLD, s_vec);
+      s_buf[s * RR_LANES + lane] = col_piece(jb, s, mp, s_vec);
+      s_buf[WJ + s * RR_LANES + lane] = row_piece(jb, s, mp, s_vec);
     }
     sync();
 #pragma unroll
@@ -1035,7 +1053,7 @@ struct Wave {
       const int d = lane + RR_LANES * s;
       float sum = 0.0f;
       if (d < D.nv) {
-        sum = s_qLD[2 * (opaque(dofc1[s]) & 0xFFFF)] * s_vec[d];
+        sum = mp[2 * (opaque(dofc1[s]) & 0xFFFF)] * s_vec[d];
         sum += merge_pieces(s_buf, jb.own[s] & 255, (jb.own[s] >> 8) & 255, D.cmax);
         sum += merge_pieces(s_buf + WJ, (jb.own[s] >> 16) & 255, (int)((unsigned)jb.own[s] >> 24), D.rmax);
       }
@@ -1376,11 +1394,117 @@ struct Wave {
     cost = 0.5f * part[0] + gauss;
   }
 
+  // ---------------------------------------------------------------- Newton solver [UP mjx solver, SolverType.NEWTON; REF Rodent_Env_Brax.py:42-45]
+  // H = M + J' diag(D * active) J.  Every constraint row of these models lives on ONE ancestor chain (a contact's body, a limited
+  // dof), so J' D J couples a dof only with its own ancestors: H has exactly M's tree sparsity (entry Madr[i] + p <-> dof i and
+  // its p-th ancestor) and is held as a second pair array, factorised and inverted by the SAME level schedules (address shift),
+  // and solved by the same balanced jobs.  The contacts in penetration are walked like J' f (ballot + readlane broadcast of the
+  // contact's frame); every dof lane on the chain forms its four pyramid-row entries, the rows go through the pose cells, and the
+  // lane adds D_k r_k[i] r_k[anc_p(i)] along its own row of H.
+  __device__ __forceinline__ void newton_hessian() {
+    const int RS = (D.nv + 3) & ~3;                      // row stride in the pose cells: 4 rows of nv floats (4 nv <= 7 nbody + 4, host check)
+    for (int e = lane; e < D.nM + 20; e += RR_LANES) *(rr_f2*)(s_H + 2 * e) = *(const rr_f2*)(s_Mp + 2 * e);     // H <- M (with the schedule cells)
+    float cd[NVS][6];
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) {
+      const int d = lane + RR_LANES * s;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) cd[s][k] = d < D.nv ? s_cdof[6 * d + k] : 0.0f;
+    }
+    sync();
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) {        // limit rows: J = +-e_d
+      if (lim_act[s] && lim_jar[s] < 0) { rr_f2* h = (rr_f2*)(s_H + 2 * (opaque(dofc1[s]) & 0xFFFF)); *h += rr_f2{lim_D[s], lim_D[s]}; }
+    }
+#pragma unroll
+    for (int cs = 0; cs < NCS; ++cs) {
+      unsigned long long mask = __ballot(con_act[cs]);
+      while (mask) {
+        const int l = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        auto bc = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+        const float mu = bc(con_mu[cs]), Dc = bc(con_D[cs]);
+        const v3 off = mk3(bc(con_off[cs][0]), bc(con_off[cs][1]), bc(con_off[cs][2]));
+        const v3 fn = mk3(bc(con_fr[cs][0]), bc(con_fr[cs][1]), bc(con_fr[cs][2])), f1 = mk3(bc(con_fr[cs][3]), bc(con_fr[cs][4]), bc(con_fr[cs][5])),
+                 f2 = mk3(bc(con_fr[cs][6]), bc(con_fr[cs][7]), bc(con_fr[cs][8]));
+        float a[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = bc(con_jar[cs][k]) < 0 ? Dc : 0.0f;
+        const int ld = __builtin_amdgcn_readlane(con_leaf[cs], l);
+        float r[NVS][4];
+        bool on[NVS];
+#pragma unroll
+        for (int s = 0; s < NVS; ++s) {
+          const int d = lane + RR_LANES * s;
+          on[s] = d < D.nv && d <= ld && ld <= (opaque(dofc1[s]) >> 16);
+          const v3 jp = mk3(cd[s][3], cd[s][4], cd[s][5]) + cross(mk3(cd[s][0], cd[s][1], cd[s][2]), off);
+          const float jn = dot(fn, jp), j1 = dot(f1, jp), j2 = dot(f2, jp);
+          r[s][0] = on[s] ? jn + mu * j1 : 0.0f; r[s][1] = on[s] ? jn - mu * j1 : 0.0f;
+          r[s][2] = on[s] ? jn + mu * j2 : 0.0f; r[s][3] = on[s] ? jn - mu * j2 : 0.0f;
+          if (d < D.nv) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s_buf[k * RS + d] = r[s][k];
+          }
+        }
+        sync();
+#pragma unroll
+        for (int s = 0; s < NVS; ++s) {
+          if (s > 0 && ld < RR_LANES * s) continue;            // wave-uniform: no chain dof in this slot
+          if (on[s]) {
+            const int madr = opaque(dofc1[s]) & 0xFFFF, dep = opaque(dofc0[s]) & 255;
+            const float w0 = a[0] * r[s][0], w1 = a[1] * r[s][1], w2 = a[2] * r[s][2], w3 = a[3] * r[s][3];
+            for (int p = 0; p <= dep; ++p) {
+              const int j = s_anc[madr + p];
+              const float v = w0 * s_buf[j] + w1 * s_buf[RS + j] + w2 * s_buf[2 * RS + j] + w3 * s_buf[3 * RS + j];
+              rr_f2* h = (rr_f2*)(s_H + 2 * (madr + p));
+              *h += rr_f2{v, v};
+            }
+          }
+        }
+        sync();       // the row cells are rewritten by the next contact
+      }
+    }
+  }
+  // factor + inverse factor of H in its pair array (both halves hold H), 1/D in dinvH
+  __device__ __forceinline__ void newton_factor() {
+    const int delta = (int)((D.o_H - D.o_qLD) * sizeof(float));
+    int ment[NME];
+    load_ment(ment);
+    if (lane < 8) s_H[2 * D.nM + lane] = (lane >> 1) == 1 ? 1.0f : 0.0f;     // cells ZERO, ONE, TRASH (+ pad)
+    sync();
+    run_levels<true, true>(T.factor3, D.nfac, delta);
+    sync();
+#pragma unroll
+    for (int s = 0; s < NVS; ++s) {
+      const int d = lane + RR_LANES * s;
+      dinvH[s] = d < D.nv ? 1.0f / s_H[2 * (opaque(dofc1[s]) & 0xFFFF)] : 0.0f;
+      if (d < D.nv) *(rr_f2*)(s_buf + 2 * d) = rr_f2{dinvH[s], dinvH[s]};
+    }
+    sync();
+#pragma unroll
+    for (int it = 0; it < NME; ++it) {
+      const int ij = ment[it];
+      if (ij >= 0) {
+        const int i = ij & 255, j = ij >> 8;
+        if (i != j) *(rr_f2*)(s_H + 2 * (lane + RR_LANES * it)) *= *(const rr_f2*)(s_buf + 2 * i);
+      }
+    }
+    sync();
+    run_levels<false, true>(T.linv, D.ninv, delta);
+    sync();
+  }
+
   __device__ __forceinline__ void update_gradient() {
 #pragma unroll
     for (int s = 0; s < NVS; ++s) { grad[s] = Ma[s] - qfrc_smooth[s] - qfrc_con[s]; Mgrad[s] = grad[s]; }
     for (int rep = 0; rep < RR_REP_SOLVE; ++rep) { float t_[NVS]; for (int s = 0; s < NVS; ++s) t_[s] = grad[s]; ldl_solve(t_); }
-    ldl_solve(Mgrad);
+    if (NEWTON) {            // Mgrad = H^-1 grad
+      newton_hessian();
+      newton_factor();
+      ldl_solve_on(Mgrad, s_H, dinvH);
+    } else {
+      ldl_solve(Mgrad);
+    }
   }
 
   // [UP mjx solver._Context.create]: Jaref, Ma, constraint state (and gradient/search) at `qacc`
@@ -1447,7 +1571,8 @@ struct Wave {
   template <bool PROF>
   __device__ __forceinline__ void linesearch() {
     float red[4] = {0, 0, 0, 0};
-    put_vec(search);   // mv = M search is carried by the caller's recurrence
+    put_vec(search);   // CG: mv = M search is carried by the caller's recurrence; Newton: an explicit product with the copy of M
+    if (NEWTON) mul_m_on(mv, s_Mp);
     for (int rep = 0; rep < RR_REP_JAC; ++rep) { float t_[NCS][4]; jac_mul(t_, s_vec); asm volatile("" :: "v"(t_[0][0]), "v"(t_[0][1]), "v"(t_[0][2]), "v"(t_[0][3]) : "memory"); }
     jac_mul(con_jv, s_vec);
     stamp<PROF>(16);
@@ -1592,7 +1717,7 @@ struct Wave {
 #pragma unroll
       for (int s = 0; s < NVS; ++s) bt[0] += grad[s] * (Mgrad[s] - pm[s]);
       wave_sum_n<2>(bt);
-      const float beta = fmaxf(0.0f, bt[0] / fmaxf(RR_MINVAL, bt[1]));
+      const float beta = NEWTON ? 0.0f : fmaxf(0.0f, bt[0] / fmaxf(RR_MINVAL, bt[1]));      // Newton: search = -Mgrad
 #pragma unroll
       for (int s = 0; s < NVS; ++s) { search[s] = -Mgrad[s] + beta * search[s]; mv[s] = -grad[s] + beta * mv[s]; }
       ++niter;
@@ -1674,7 +1799,7 @@ static __device__ __forceinline__ RRIO load_io() {
 #endif
 }
 
-template <int NBS, int NVS, int NCS, bool PROF, bool DBG, class DT>
+template <int NBS, int NVS, int NCS, bool PROF, bool DBG, class DT, bool NEWTON = false>
 __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(const RRDims Dk, const RRTables T, const RRIO io_kernarg, const int num_envs,
                                                            const int n_frames) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1683,7 +1808,7 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
   // the level schedules address LDS by absolute byte address: the dynamic segment must start at 0 (no static LDS here)
   if ((unsigned)(size_t)(float __attribute__((address_space(3)))*)lds != 0u) __builtin_trap();
   const DT D(Dk);
-  Wave<NBS, NVS, NCS, DT> w(D, T, lds);
+  Wave<NBS, NVS, NCS, DT, NEWTON> w(D, T, lds);
   int lane = threadIdx.x;
   RRIO io = load_io();
   if (io.env_map) {          // a permutation of 0 .. num_envs-1 (host-checked length); environments are independent, so the mapping
@@ -1724,6 +1849,7 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
   }
   w.work = 0;
   for (int i = lane; i < D.nv; i += RR_LANES) w.s_arm[i] = T.dof_f[16 * i];
+  if (NEWTON) for (int i = lane; i < (D.nM + 3) / 4; i += RR_LANES) ((int*)w.s_anc)[i] = T.anc4[i];
   if (lane < 6) w.s_cdof[6 * D.nv + lane] = 0.0f;
   if (lane == 0) w.s_qvel[D.nv] = 0.0f;
   if (lane < 40) w.s_qLD[2 * D.nM + lane] = 0.0f;        // cells ZERO .. pad, and the 16 zero cells behind them (pairs)
@@ -1837,6 +1963,10 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
     w.mass_matrix();
     w.template stamp<PROF>(4);
     if (dg) for (int e = lane; e < D.nM; e += RR_LANES) dg[D.g_qM + e] = w.s_qLD[2 * e];
+    if (NEWTON) {      // M itself is needed all through the Newton iterations (M * search, H = M + ...): keep a copy of the pair array
+      for (int e = lane; e < D.nM + 20; e += RR_LANES) *(rr_f2*)(w.s_Mp + 2 * e) = *(const rr_f2*)(w.s_qLD + 2 * e);
+      w.sync();
+    }
     {   // the substep's only product with M itself: M * qacc_warmstart, for the solver's warm-start context
       float wv[NVS];
 #pragma unroll

@@ -85,11 +85,12 @@ class State:
 class System:
     """The few `sys.*` attributes the reference env touches [REF Rodent_Env_Brax.py:82-89]."""
 
-    def __init__(self, blob_path: str, iterations: int, ls_iterations: int):
+    def __init__(self, blob_path: str, iterations: int, ls_iterations: int, solver: str = "cg"):
         from .. import mjcf
         self.blob_path = blob_path
         self.tables = mjcf.load_blob(blob_path)
-        self.model = hip.Model(blob_path, iterations=iterations, ls_iterations=ls_iterations)
+        self.model = hip.Model(blob_path, iterations=iterations, ls_iterations=ls_iterations, solver=solver)
+        self.solver = solver.lower()
         d = self.model.dims
         self.nq, self.nv, self.nu, self.na, self.nbody = d.nq, d.nv, d.nu, d.na, d.nbody
         self.obs_dim = d.obs_dim

@@ -39,11 +39,11 @@ class Rodent(PipelineEnv):
         device=None,
         **kwargs,
     ):
-        if solver.lower() != "cg":
-            raise NotImplementedError("only the CG solver is implemented (the reference launcher uses cg)")
+        if solver.lower() not in ("cg", "newton"):       # [REF Rodent_Env_Brax.py:42-45]
+            raise ValueError(f"solver must be 'cg' or 'newton', got {solver!r}")
         if vision:
             raise NotImplementedError("vision observations are not part of the reference obs either")
-        sys = System(assets.resolve_model(xml_path), iterations, ls_iterations)
+        sys = System(assets.resolve_model(xml_path), iterations, ls_iterations, solver)
         physics_steps_per_control_step = 10   # [REF Rodent_Env_Brax.py:53-57]
         kwargs["n_frames"] = kwargs.get("n_frames", physics_steps_per_control_step)
         kwargs["backend"] = "hip"

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("RR_LIB") or os.path.join(os.path.dirname(_HERE), "csr
 class RRDims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nM", "ncon", "nlimit",
                                          "nefc", "obs_dim", "iterations", "ls_iterations", "lds_bytes", "dbg_floats")] \
-        + [("timestep", C.c_float)]
+        + [("timestep", C.c_float), ("solver", C.c_int32)]
 
 
 class RRState(C.Structure):
@@ -42,7 +42,7 @@ class RREnvIO(C.Structure):
                 ("terminate_when_unhealthy", C.c_int32)]
 
 
-EXPORTS = ["rr_model_load", "rr_model_dims", "rr_model_set_solver", "rr_model_destroy", "rr_model_table", "rr_kernarg_layout", "rr_batch_create",
+EXPORTS = ["rr_model_load", "rr_model_dims", "rr_model_set_solver", "rr_model_set_solver_type", "rr_model_destroy", "rr_model_table", "rr_kernarg_layout", "rr_batch_create",
            "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset", "rr_pipeline_step_to", "rr_env_step_to",
            "rr_compute_gae", "rr_mlp_forward", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_schedule", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
 
@@ -60,6 +60,7 @@ def lib():
         L.rr_model_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
         L.rr_model_dims.argtypes = [C.c_void_p, C.POINTER(RRDims)]
         L.rr_model_set_solver.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        L.rr_model_set_solver_type.argtypes = [C.c_void_p, C.c_int32]
         L.rr_model_destroy.argtypes = [C.c_void_p]
         L.rr_model_destroy.restype = None
         L.rr_model_table.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
@@ -109,9 +110,11 @@ def _ptr(t: Optional[torch.Tensor], dtype=torch.float32, numel: Optional[int] = 
 class Model:
     """A compiled model loaded from an RRM1 blob (host side)."""
 
-    def __init__(self, blob_path: str, iterations: Optional[int] = None, ls_iterations: Optional[int] = None):
+    def __init__(self, blob_path: str, iterations: Optional[int] = None, ls_iterations: Optional[int] = None, solver: Optional[str] = None):
         self.h = C.c_void_p()
         _check(lib().rr_model_load(blob_path.encode(), C.byref(self.h)))
+        if solver is not None:
+            _check(lib().rr_model_set_solver_type(self.h, {"cg": 1, "newton": 2}[solver.lower()]))
         if iterations is not None:
             d = self.dims
             _check(lib().rr_model_set_solver(self.h, iterations, ls_iterations if ls_iterations is not None else d.ls_iterations))

@@ -38,6 +38,7 @@ typedef struct rr_dims {
   int32_t lds_bytes;                 /* dynamic LDS one environment (= one wavefront) uses */
   int32_t dbg_floats;                /* floats per env of the debug dump (rr_debug_layout) */
   float timestep;
+  int32_t solver;                    /* 1 = CG, 2 = Newton (mjtSolver; opt.solver [REF Rodent_Env_Brax.py:42-45]) */
 } rr_dims;
 
 /* physics state of the batch: what survives between `pipeline_step` calls (mjx.Data qpos, qvel, act,
@@ -87,6 +88,10 @@ int rr_model_load(const char* blob_path, rr_model** out);
 int rr_model_dims(const rr_model* m, rr_dims* out);
 /* opt.iterations / opt.ls_iterations override [REF Rodent_Env_Brax.py:46-47] (before rr_batch_create) */
 int rr_model_set_solver(rr_model* m, int32_t iterations, int32_t ls_iterations);
+/* opt.solver = {'cg': 1, 'newton': 2} [REF Rodent_Env_Brax.py:42-45] (before rr_batch_create).  Newton: H = M + J' diag(D active) J
+ * has M's tree sparsity for these models and runs through the same factorisation schedules in a second LDS array (csrc/rr_kernel.h
+ * newton_hessian); available for the single-rodent models (RR_EUNSUPPORTED otherwise); ~40 KB of LDS per environment. */
+int rr_model_set_solver_type(rr_model* m, int32_t solver);
 void rr_model_destroy(rr_model* m);
 /* Static model tables as the LOADED model holds them (the integer ids the reference exposes through `sys` / `Contact`:
  * "con_geom1", "con_geom2" = Contact.geom1 / geom2 [NB mjcf.ipynb:917-921], "con_body1", "con_body2" (+1 of brax's

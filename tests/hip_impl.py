@@ -8,9 +8,9 @@ DEV = "cuda:0"
 
 
 class HipImpl:
-    def __init__(self, model_name, n, iterations, debug):
+    def __init__(self, model_name, n, iterations, debug, solver=None):
         from rodent_amd import assets, hip, mjcf
-        self.model = hip.Model(assets.asset_path(model_name), *iterations)
+        self.model = hip.Model(assets.asset_path(model_name), *iterations, solver=solver)
         self.batch = hip.Batch(self.model, n, torch.device(DEV))
         self.n, self.debug = n, debug
         tab = mjcf.load_blob(assets.asset_path(model_name))
@@ -49,9 +49,9 @@ class NoDiscrete:
 
 
 class HipEnvImpl:
-    def __init__(self, n, iterations, track, model_name="rodent_optimized"):
+    def __init__(self, n, iterations, track, model_name="rodent_optimized", solver="cg"):
         from rodent_amd import envs
-        self.env = envs.get_environment("rodent", track_pos=track, num_envs=n, xml_path=f"{model_name}.xml",
+        self.env = envs.get_environment("rodent", track_pos=track, num_envs=n, xml_path=f"{model_name}.xml", solver=solver,
                                         iterations=iterations[0], ls_iterations=iterations[1], device=DEV)
         self.state0 = self.env.reset(0)
 

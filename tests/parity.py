@@ -32,9 +32,10 @@ def f32r(x):
 class OracleImpl:
     """One substep / env step of a RefBatch in the given precision, in the harness' calling convention."""
 
-    def __init__(self, model_name, n, precision, iterations):
+    def __init__(self, model_name, n, precision, iterations, solver="cg"):
         self.M = ref.RefModel(assets.asset_path(model_name), precision)
         self.M.set_iterations(*iterations)
+        self.M.set_solver(solver)
         self.b = ref.RefBatch(self.M, n)
         self.n = n
         tab = mjcf.load_blob(assets.asset_path(model_name))
@@ -53,13 +54,13 @@ class OracleImpl:
         return out
 
 
-def rollout_inputs(model_name, n, steps, iterations, seed, n_frames=1, reset_every=None, z_range=(0.03, 0.5)):
+def rollout_inputs(model_name, n, steps, iterations, seed, n_frames=1, reset_every=None, z_range=(0.03, 0.5), solver="cg"):
     """The float64 oracle's own trajectory under fresh U(-1,1) actions: the list of (state, ctrl) every implementation is
     started from.  Envs that leave the healthy range (or `reset_every` steps) restart from their initial state."""
     from tests import util
     st0, M, tab = util.settled_states(ref, model_name, n, seed=seed, iterations=iterations)
     st0 = {k: f32r(v) for k, v in st0.items()}
-    A = OracleImpl(model_name, n, "f64", iterations)
+    A = OracleImpl(model_name, n, "f64", iterations, solver)
     rng = np.random.default_rng(seed + 1)
     st = {k: v.copy() for k, v in st0.items()}
     age = np.zeros(n, int)
@@ -103,7 +104,7 @@ def substep_ladder(impl, seq, A, gap_impl, report=None):
     con_dist, lim_pos, lim_D, lim_aref, niter."""
     rows = {k: [] for k in ("qpos", "qvel", "qacc", "act")}
     gaps = {k: [] for k in rows}
-    niter_eq, niter_eq_gap, n_samples = 0, 0, 0
+    niter_eq, niter_eq_gap, niter_eq_f32, niter_w1, n_samples = 0, 0, 0, 0, 0
     edge_flips = 0.0
     lim_err = {"lim_D": 0.0, "lim_aref": 0.0}
     for st, ctrl in seq:
@@ -119,12 +120,15 @@ def substep_ladder(impl, seq, A, gap_impl, report=None):
                 lim_err[k] = max(lim_err[k], float((np.abs(got[k] - want[k])[act] / np.maximum(np.abs(want[k][act]), 1e-6)).max()))
         niter_eq += int((got["niter"] == want["niter"]).sum())
         niter_eq_gap += int((gp["niter"] == want["niter"]).sum())
+        niter_eq_f32 += int((got["niter"] == gp["niter"]).sum())
+        niter_w1 += int((np.abs(got["niter"] - want["niter"]) <= 1).sum())
         n_samples += len(want["niter"])
         for k, f in (("qpos", "qpos"), ("qvel", "qvel"), ("qacc", "qacc_warmstart"), ("act", "act")):
             scale = np.maximum(np.abs(want[f]).max(1), 1.0) if k == "qacc" else 1.0
             rows[k].append(np.abs(got[f] - want[f]).max(1) / scale)
             gaps[k].append(np.abs(gp[f] - want[f]).max(1) / scale)
-    out = dict(niter_equal=niter_eq / n_samples, niter_equal_f32_oracle=niter_eq_gap / n_samples, samples=n_samples,
+    out = dict(niter_equal=niter_eq / n_samples, niter_equal_f32_oracle=niter_eq_gap / n_samples, niter_equal_to_f32_oracle=niter_eq_f32 / n_samples,
+               niter_within_1=niter_w1 / n_samples, samples=n_samples,
                activity_flips_at_edge=edge_flips / (2 * len(seq)), limit_rows=lim_err, quantiles=[])
     for k in rows:
         out["quantiles"] += quantile_rows(k, np.concatenate(rows[k]), np.concatenate(gaps[k]))
@@ -136,9 +140,16 @@ def substep_ladder(impl, seq, A, gap_impl, report=None):
 SUBSTEP_FLOORS = dict(qpos=2e-7, qvel=2e-5, qacc=2e-6, act=1e-7)     # absolute; a few float32 ulps of the quantity's scale
 
 
-def assert_substep_criteria(out):
+def assert_substep_criteria(out, newton=False):
+    """newton: the float32 Newton run stops one iteration after the float64 one in ~80 % of the samples (the gradient norm levels
+    off at float32 rounding just above the tolerance the float64 run meets; the oracle's own float32 build shows it: 18 % equal,
+    100 % within one).  C2 is then taken against the float32 oracle (two float32 builds of the oracle agree in 99.4 %, the build
+    with the seeded bug in 94 %), plus |niter - float64's| <= 1."""
     check_quantiles(out["quantiles"], SUBSTEP_FLOORS)
-    assert out["niter_equal"] >= 0.90, out["niter_equal"]
+    if newton:
+        assert out["niter_equal_to_f32_oracle"] >= 0.90 and out["niter_within_1"] >= 0.99, (out["niter_equal_to_f32_oracle"], out["niter_within_1"])
+    else:
+        assert out["niter_equal"] >= 0.90, out["niter_equal"]
     assert out["limit_rows"]["lim_D"] < 1e-3 and out["limit_rows"]["lim_aref"] < 1e-3, out["limit_rows"]
 
 
@@ -154,8 +165,8 @@ def obs_segments(tab):
 
 
 class OracleEnvImpl(OracleImpl):
-    def __init__(self, model_name, n, precision, iterations, track, z_range=(0.03, 0.5)):
-        super().__init__(model_name, n, precision, iterations)
+    def __init__(self, model_name, n, precision, iterations, track, z_range=(0.03, 0.5), solver="cg"):
+        super().__init__(model_name, n, precision, iterations, solver)
         self.track, self.z = np.asarray(track, np.float64), z_range
 
     def env_step(self, st, ctrl, cur_frame):

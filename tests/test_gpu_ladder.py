@@ -61,6 +61,40 @@ def test_teacher_forced_substeps_rodent_pair(oracle_built):
     parity.assert_substep_criteria(out)
 
 
+def test_teacher_forced_substeps_newton(oracle_built):
+    """solver = Newton (the Hessian M + J'DJ factored per iteration through the level schedules of M)."""
+    N, it = 16, (4, 8)
+    seq, A, tab = parity.rollout_inputs("rodent_optimized", N, 400, it, seed=41, solver="newton")
+    out = parity.substep_ladder(HipImpl("rodent_optimized", N, it, True, solver="newton"), seq, A,
+                                parity.OracleImpl("rodent_optimized", N, "f32", it, solver="newton"))
+    _report("substeps_newton4", out)
+    parity.assert_substep_criteria(out, newton=True)
+    out = parity.substep_ladder(NoDiscrete(HipImpl("rodent_optimized", N, it, False, solver="newton"), A), seq[:200], A,
+                                parity.OracleImpl("rodent_optimized", N, "f32", it, solver="newton"))
+    _report("substeps_newton4_production", out)
+    parity.check_quantiles(out["quantiles"], parity.SUBSTEP_FLOORS)
+
+
+def test_teacher_forced_env_steps_newton(oracle_built):
+    """The reference's default env configuration [REF Rodent_Env_Brax.py:42-45, solver='cg' | 'newton'] with solver='newton'."""
+    N, T, it = 16, 200, (4, 8)
+    track = util.synthetic_track()
+    seq, A0, tab = parity.rollout_inputs("rodent_optimized", N, T, it, seed=45, n_frames=10, reset_every=150, solver="newton")
+    rng = np.random.default_rng(46)
+    seq = [(st, ctrl, rng.integers(0, 260, N).astype(np.int32)) for st, ctrl in seq]
+    A = parity.OracleEnvImpl("rodent_optimized", N, "f64", it, track, solver="newton")
+    out = parity.envstep_ladder(HipEnvImpl(N, it, track, solver="newton"), seq, A,
+                                parity.OracleEnvImpl("rodent_optimized", N, "f32", it, track, solver="newton"), tab)
+    _report("envsteps_newton4", out)
+    parity.check_quantiles(out["quantiles"], parity.ENV_FLOORS)
+
+
+def test_newton_is_refused_for_models_without_an_instance():
+    from rodent_amd import assets, hip
+    with pytest.raises(RuntimeError, match="Newton"):
+        hip.Model(assets.asset_path("rodent_pair"), 4, 8, solver="newton")
+
+
 def test_teacher_forced_1000_env_steps(oracle_built):
     N, T = 16, 1000
     track = util.synthetic_track()

@@ -27,3 +27,20 @@ def test_a_five_percent_modelling_error_is_rejected(inputs):
     print(out["quantiles"])
     with pytest.raises(AssertionError):
         parity.assert_substep_criteria(out)
+
+
+@pytest.fixture(scope="module")
+def newton_inputs(oracle_built):
+    return parity.rollout_inputs("rodent_optimized", 8, 120, (4, 8), seed=23, solver="newton")
+
+
+def test_newton_criteria_pass_for_a_differently_rounded_build_and_reject_the_bug(newton_inputs):
+    seq, A, tab = newton_inputs
+    gap = parity.OracleImpl("rodent_optimized", 8, "f32", (4, 8), solver="newton")
+    out = parity.substep_ladder(parity.OracleImpl("rodent_optimized", 8, "f32fma", (4, 8), solver="newton"), seq, A, gap)
+    print(out)
+    assert out["niter_equal"] < 0.5                     # why C2 is taken against the float32 oracle for Newton (see assert_substep_criteria)
+    parity.assert_substep_criteria(out, newton=True)
+    out = parity.substep_ladder(parity.OracleImpl("rodent_optimized", 8, "f32bug", (4, 8), solver="newton"), seq, A, gap)
+    with pytest.raises(AssertionError):
+        parity.assert_substep_criteria(out, newton=True)
