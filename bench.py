@@ -81,7 +81,7 @@ def sq_counters():
         return {}
 
 
-def cpu_baseline(n_envs=512, steps=100):
+def cpu_baseline(n_envs=512, steps=100, solver="cg", iterations=(8, 8)):
     """The oracle (kind 'port': our C restatement; the reference JAX path cannot run here) timed on the host cores."""
     from oracle import ref
     from rodent_amd import assets, mjcf
@@ -91,7 +91,8 @@ def cpu_baseline(n_envs=512, steps=100):
     path = assets.asset_path(MODEL)
     m = mjcf.load_blob(path)
     M = ref.RefModel(path, "f32")
-    M.set_iterations(8, 8)
+    M.set_iterations(*iterations)
+    M.set_solver(solver)
     rng = np.random.default_rng(0)
     datas = []
     for e in range(n_envs):
@@ -117,6 +118,9 @@ def parse():
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5), help="BASELINE.json config (2 = the headline metric's)")
     ap.add_argument("--num-envs", type=int, default=None, help="envs per GPU (default 2048; 4096 for config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--solver", default="cg", choices=("cg", "newton"), help="config 2 only; the headline configuration is cg 8/8")
+    ap.add_argument("--iterations", type=int, default=8)
+    ap.add_argument("--ls-iterations", type=int, default=8)
     args = ap.parse_args()
     args.protocol = "driver" if (args.steps is not None or args.warmup is not None) else "survey-8d"
     if args.config == 3:
@@ -200,8 +204,8 @@ def main():
         repeats_ms = [elapsed / len(timed) * 1e3]
     else:
         if args.config == 2:
-            env = envs.get_environment("rodent", track_pos=synthetic_track(), num_envs=N, xml_path=f"{model}.xml",
-                                       terminate_when_unhealthy=True, solver="cg", iterations=8, ls_iterations=8, device=dev)
+            env = envs.get_environment("rodent", track_pos=synthetic_track(), num_envs=N, xml_path=f"{model}.xml", terminate_when_unhealthy=True,
+                                       solver=args.solver, iterations=args.iterations, ls_iterations=args.ls_iterations, device=dev)
             wenv = wrappers.wrap(env, episode_length=150, action_repeat=1)
             keys = jax_random.split(jax_random.fold_in(jax_random.PRNGKey(0), rank), N)
             state = wenv.reset(keys)
@@ -210,7 +214,8 @@ def main():
             def one_step(state):
                 action = torch.empty(N, nu, device=dev).uniform_(-1.0, 1.0, generator=gen)      # fresh U(-1,1) draws, one launch
                 return wenv.step(state, action)
-            workload = f"{model}.xml random-action rollout, Rodent.step through Episode(150)+AutoReset wrappers, CG 8/8, n_frames 10"
+            workload = (f"{model}.xml random-action rollout, Rodent.step through Episode(150)+AutoReset wrappers, "
+                        f"{args.solver.upper()} {args.iterations}/{args.ls_iterations}, n_frames 10")
         else:
             # ---- config 5: rodent_pair.xml (two replicated rodents, nv 146, 114 contacts), physics only (pipeline_step)
             from rodent_amd import assets, hip, mjcf
@@ -279,7 +284,7 @@ def main():
             "cpu_baseline": None,
         }
         if world == 1 and not args.no_cpu_baseline and args.config == 2:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(solver=args.solver, iterations=(args.iterations, args.ls_iterations))
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -3,6 +3,7 @@
 #include "../../include/rodent_rr.h"
 #include "rr_kernel.h"
 #include "rr_mlp.h"
+#include "rr_ppo.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -416,6 +417,47 @@ extern "C" int rr_compute_gae(const float* truncation, const float* termination,
     return fail(RR_EINVAL, "rr_compute_gae: bad argument");
   hipLaunchKernelGGL(rr_gae_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, truncation, termination, rewards,
                      values, bootstrap_value, T, B, lambda_, discount, vs, advantages);
+  HIPCHK(hipGetLastError());
+  return RR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ PPO: loss + gradient w.r.t. the network outputs
+static void ppo_blocks(int T, int B, int* nblk1, int* nblk2) {
+  *nblk1 = (B + 255) / 256;
+  const long n = (long)T * B;
+  *nblk2 = (int)std::min<long>((n + 7) / 8, 1024);
+}
+extern "C" size_t rr_ppo_loss_workspace_bytes(int32_t T, int32_t B) {
+  if (T <= 0 || B <= 0) return 0;
+  int n1, n2;
+  ppo_blocks(T, B, &n1, &n2);
+  return rr_align_up((size_t)2 * T * B * sizeof(float), 8) + ((size_t)2 * n1 + (size_t)3 * n2) * sizeof(double);
+}
+extern "C" int rr_ppo_loss(const float* policy_logits, const float* values, const float* raw_action, const float* log_prob, const float* reward,
+                           const float* discount, const float* truncation, const int64_t* idx, const float* noise, int32_t T, int32_t B, int32_t A,
+                           const rr_ppo_cfg* cfg, float* grad_logits, float* grad_values, float* metrics, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+  if (!policy_logits || !values || !raw_action || !log_prob || !reward || !discount || !truncation || !noise || !cfg || !grad_logits ||
+      !grad_values || !metrics || !workspace || T <= 0 || B <= 0 || A <= 0)
+    return fail(RR_EINVAL, "rr_ppo_loss: bad argument");
+  if (workspace_bytes < rr_ppo_loss_workspace_bytes(T, B) || ((uintptr_t)workspace & 7))
+    return fail(RR_EINVAL, "rr_ppo_loss: workspace too small (rr_ppo_loss_workspace_bytes) or not 8-byte aligned");
+  RRPpoArgs P;
+  memset(&P, 0, sizeof(P));
+  P.logits = policy_logits; P.values = values; P.raw_action = raw_action; P.log_prob = log_prob; P.reward = reward; P.discount = discount;
+  P.truncation = truncation; P.idx = idx; P.noise = noise; P.T = T; P.B = B; P.A = A;
+  P.entropy_cost = cfg->entropy_cost; P.discounting = cfg->discounting; P.reward_scaling = cfg->reward_scaling; P.gae_lambda = cfg->gae_lambda;
+  P.clipping_epsilon = cfg->clipping_epsilon; P.min_std = cfg->min_std; P.normalize_advantage = cfg->normalize_advantage;
+  P.grad_logits = grad_logits; P.grad_values = grad_values; P.metrics = metrics;
+  ppo_blocks(T, B, &P.nblk1, &P.nblk2);
+  char* w = (char*)workspace;
+  P.vs = (float*)w; P.adv = P.vs + (size_t)T * B;
+  P.part_adv = (double*)(w + rr_align_up((size_t)2 * T * B * sizeof(float), 8));
+  P.part_loss = P.part_adv + 2 * P.nblk1;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(rr_ppo_gae_kernel, dim3(P.nblk1), dim3(256), 0, st, P);
+  hipLaunchKernelGGL(rr_ppo_loss_kernel, dim3(P.nblk2), dim3(256), 0, st, P);
+  hipLaunchKernelGGL(rr_ppo_metrics_kernel, dim3(1), dim3(64), 0, st, P);
   HIPCHK(hipGetLastError());
   return RR_OK;
 }

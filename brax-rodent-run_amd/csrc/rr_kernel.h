@@ -876,16 +876,18 @@ struct Wave {
         const rr_f2 va = lds_ld2(a8);
         rr_f2 vp = {1.0f, 1.0f};
         if (DIV) vp = lds_ld2(a8 - (e.w & 0xFFFF) + 8);
+        const int fl = __builtin_amdgcn_readfirstlane(e.w) >> 16;
         rr_f2 vb[4], vo[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { vb[j] = lds_ld2(b8 + 8 * j); vo[j] = lds_ld2(d8[j]); }
+        for (int j = 0; j < 4; ++j) vb[j] = lds_ld2(b8 + 8 * j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vo[j] = lds_ld2(d8[j]);    // also on rows that do not apply: reading the targets only on the flagged rows measured +2.2 % (late reads)
         rr_f2 t = va;
         if (DIV) {
           rr_f2 r = {__builtin_amdgcn_rcpf(vp.x), __builtin_amdgcn_rcpf(vp.y)};
           r = r * (2.0f - vp * r);
           t *= r;
         }
-        const int fl = __builtin_amdgcn_readfirstlane(e.w) >> 16;
         if (DIV) {       // several contribution ranks per target: accumulate, apply on the flagged row
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[j] += vb[j] * t;

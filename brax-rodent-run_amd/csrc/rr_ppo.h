@@ -1,0 +1,174 @@
+// The loss half of one PPO minibatch update and its gradient with respect to the network outputs, three launches.
+//
+// What `brax.training.agents.ppo.losses.compute_ppo_loss` [UP; REF brax_rodent_run_ppo.py:97-114]
+// computes after the two network forwards -- truncation-aware GAE, device-local advantage normalisation, tanh-normal
+// log-probabilities, the clipped surrogate, the value loss, the sampled entropy -- and what reverse-mode differentiation of it
+// hands back to the networks (d total_loss / d policy_logits, d total_loss / d values).  Composed from tensor ops this is ~45
+// launches per minibatch (forward) plus as many in the backward; here:
+//   K1 rr_ppo_gae_kernel    one thread per trajectory: reverse scan, vs and advantages, block sums of adv and adv^2 (double)
+//   K2 rr_ppo_loss_kernel   32 lanes per sample (one action dimension per lane, coalesced rows): log-prob, entropy, the three
+//                           loss terms (block sums, double) and the gradient rows
+//   K3 rr_ppo_metrics_kernel  the four scalars of the metrics dict
+// No atomics: every reduction is a fixed tree over per-block partial sums, so a replayed HIP graph reproduces the eager result
+// bit for bit.  The minibatch is addressed THROUGH the permutation (`idx`), so the five gathered copies of the batch leaves
+// (raw_action, log_prob, reward, discount, truncation) are never made.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct RRPpoArgs {
+  // network outputs on the gathered minibatch, time-major: logits [(T+1)*B][2A] (row t*B + b; the last B rows are the bootstrap
+  // observation's and carry no gradient), values [(T+1)*B]
+  const float* logits; const float* values;
+  // batch leaves, batch-major as the unroll buffer holds them: raw_action [R][T][A], log_prob/reward/discount/truncation [R][T];
+  // idx [B] selects the minibatch rows (NULL = rows 0..B-1)
+  const float* raw_action; const float* log_prob; const float* reward; const float* discount; const float* truncation;
+  const int64_t* idx;
+  const float* noise;            // [T*B][A] standard normal draws of the entropy estimate (time-major, like the logits)
+  int T, B, A;
+  float entropy_cost, discounting, reward_scaling, gae_lambda, clipping_epsilon, min_std;
+  int normalize_advantage;
+  float* grad_logits;            // [(T+1)*B][2A]
+  float* grad_values;            // [(T+1)*B]
+  float* metrics;                // total_loss, policy_loss, v_loss, entropy_loss
+  float* vs; float* adv;         // workspace [T*B] each
+  double* part_adv;              // [2 * nblk1]
+  double* part_loss;             // [3 * nblk2]
+  int nblk1, nblk2;
+};
+
+template <int N>
+static __device__ __forceinline__ void rr_block_sum(double (&v)[N], double* sh /* [N * 4] */, double* out, int stride) {
+  // 256 threads = 4 waves: wave sums by shuffles, then the four wave sums through LDS
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int k = 0; k < N; ++k) sh[k * 4 + w] = v[k];
+  __syncthreads();
+  if (threadIdx.x == 0)
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k * stride] = (sh[k * 4] + sh[k * 4 + 1]) + (sh[k * 4 + 2] + sh[k * 4 + 3]);
+}
+
+__global__ __launch_bounds__(256) void rr_ppo_gae_kernel(const RRPpoArgs P) {
+  __shared__ double sh[8];
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  const int T = P.T, B = P.B;
+  double s[2] = {0.0, 0.0};
+  if (b < B) {
+    const size_t row = (size_t)(P.idx ? P.idx[b] : b) * T;
+    const float vb = P.values[(size_t)T * B + b];
+    float acc = 0.0f;
+    for (int t = T - 1; t >= 0; --t) {     // vs_t - v_t = delta_t + gamma (1-term_t)(1-trunc_t) lambda (vs_{t+1} - v_{t+1})
+      const size_t i = (size_t)t * B + b;
+      const float tr = P.truncation[row + t], mask = 1.0f - tr, nt = 1.0f - (1.0f - P.discount[row + t]) * mask;
+      const float r = P.reward[row + t] * P.reward_scaling, v = P.values[i];
+      const float vnext = t == T - 1 ? vb : P.values[i + B];
+      const float delta = (r + P.discounting * nt * vnext - v) * mask;
+      acc = delta + P.discounting * nt * mask * P.gae_lambda * acc;
+      P.vs[i] = acc + v;
+    }
+    for (int t = 0; t < T; ++t) {          // advantages use vs_{t+1} (bootstrap at the end)
+      const size_t i = (size_t)t * B + b;
+      const float tr = P.truncation[row + t], mask = 1.0f - tr, nt = 1.0f - (1.0f - P.discount[row + t]) * mask;
+      const float vsn = t == T - 1 ? vb : P.vs[i + B];
+      const float a = (P.reward[row + t] * P.reward_scaling + P.discounting * nt * vsn - P.values[i]) * mask;
+      P.adv[i] = a;
+      s[0] += (double)a; s[1] += (double)a * (double)a;
+    }
+  }
+  rr_block_sum<2>(s, sh, P.part_adv + blockIdx.x, P.nblk1);
+}
+
+static __device__ __forceinline__ float rr_softplus(float x) { return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x))); }
+
+__global__ __launch_bounds__(256) void rr_ppo_loss_kernel(const RRPpoArgs P) {
+  __shared__ double sh[12];
+  __shared__ float s_stat[2];
+  const int T = P.T, B = P.B, A = P.A;
+  const int n = T * B;
+  if (threadIdx.x < 64) {                  // advantage mean / std (population) from K1's block sums
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = threadIdx.x; k < P.nblk1; k += 64) { s0 += P.part_adv[k]; s1 += P.part_adv[P.nblk1 + k]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
+    if (threadIdx.x == 0) {
+      const double mean = s0 / n, var = fmax(s1 / n - mean * mean, 0.0);
+      s_stat[0] = P.normalize_advantage ? (float)mean : 0.0f;
+      s_stat[1] = P.normalize_advantage ? 1.0f / ((float)sqrt(var) + 1e-8f) : 1.0f;
+    }
+  }
+  __syncthreads();
+  const float amean = s_stat[0], ainv = s_stat[1];
+  const int lane = threadIdx.x & 31;
+  const int P2 = 2 * A;
+  const float invn = 1.0f / (float)n;
+  const float HALF_LOG_2PI = 0.91893853320467274178f, LOG2 = 0.69314718055994530942f;
+  double acc[3] = {0.0, 0.0, 0.0};
+  // bootstrap rows: no gradient
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < B * P2; i += gridDim.x * 256) P.grad_logits[(size_t)n * P2 + i] = 0.0f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < B; i += gridDim.x * 256) P.grad_values[n + i] = 0.0f;
+  const int per_block = 256 / 32;
+  for (int smp = blockIdx.x * per_block + (threadIdx.x >> 5); smp < n; smp += gridDim.x * per_block) {
+    const int t = smp / B, b = smp - t * B;
+    const size_t row = (size_t)(P.idx ? P.idx[b] : b) * T + t;
+    const float* lg = P.logits + (size_t)smp * P2;
+    float lp = 0.0f, ent = 0.0f;
+    // pass 1: log-prob of the behaviour action under the current policy, entropy estimate (sums over the action dimensions)
+    for (int a = lane; a < A; a += 32) {
+      const float loc = lg[a], sr = lg[A + a], scale = rr_softplus(sr) + P.min_std;
+      const float raw = P.raw_action[row * A + a], z = (raw - loc) / scale, ls = logf(scale);
+      lp += -0.5f * z * z - ls - HALF_LOG_2PI - 2.0f * (LOG2 - raw - rr_softplus(-2.0f * raw));
+      const float x = loc + scale * P.noise[(size_t)smp * A + a];
+      ent += 0.5f + HALF_LOG_2PI + ls + 2.0f * (LOG2 - x - rr_softplus(-2.0f * x));
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { lp += __shfl_xor(lp, o, 32); ent += __shfl_xor(ent, o, 32); }
+    const float adv = (P.adv[smp] - amean) * ainv;
+    const float rho = expf(lp - P.log_prob[row]);
+    const float lo = 1.0f - P.clipping_epsilon, hi = 1.0f + P.clipping_epsilon;
+    const float s1 = rho * adv, s2 = fminf(fmaxf(rho, lo), hi) * adv;
+    const float inr = (rho >= lo && rho <= hi) ? 1.0f : 0.0f;
+    // d min(s1, s2) / d rho: ties split evenly (torch.minimum / jnp.minimum), the clamp passes the gradient inside its range
+    const float w = s1 < s2 ? 1.0f : (s1 > s2 ? inr : 0.5f + 0.5f * inr);
+    const float g_lp = -invn * adv * w * rho;              // d policy_loss / d log_prob
+    const float g_h = -P.entropy_cost * invn;              // d entropy_loss / d entropy
+    const float v = P.values[smp], ve = P.vs[smp] - v;
+    if (lane == 0) {
+      acc[0] += (double)fminf(s1, s2); acc[1] += (double)ve * (double)ve; acc[2] += (double)ent;
+      P.grad_values[smp] = -0.5f * invn * ve;              // d (0.25 mean(ve^2)) / d v
+    }
+    // pass 2: gradient rows
+    for (int a = lane; a < A; a += 32) {
+      const float loc = lg[a], sr = lg[A + a], scale = rr_softplus(sr) + P.min_std, is = 1.0f / scale;
+      const float raw = P.raw_action[row * A + a], z = (raw - loc) * is;
+      const float eps = P.noise[(size_t)smp * A + a], th = tanhf(loc + scale * eps);
+      const float dloc = g_lp * z * is + g_h * (-2.0f * th);
+      const float dscale = g_lp * (z * z - 1.0f) * is + g_h * (is - 2.0f * th * eps);
+      const float sig = 1.0f / (1.0f + expf(-sr));         // softplus'
+      P.grad_logits[(size_t)smp * P2 + a] = dloc;
+      P.grad_logits[(size_t)smp * P2 + A + a] = dscale * sig;
+    }
+  }
+  rr_block_sum<3>(acc, sh, P.part_loss + blockIdx.x, P.nblk2);
+}
+
+__global__ __launch_bounds__(64) void rr_ppo_metrics_kernel(const RRPpoArgs P) {
+  double s[3] = {0.0, 0.0, 0.0};
+  for (int k = threadIdx.x; k < P.nblk2; k += 64)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) s[j] += P.part_loss[j * P.nblk2 + k];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s[j] += __shfl_xor(s[j], o, 64);
+  if (threadIdx.x == 0) {
+    const double n = (double)P.T * P.B;
+    const float pl = (float)(-s[0] / n), vl = (float)(0.25 * s[1] / n), el = (float)(-(double)P.entropy_cost * s[2] / n);
+    P.metrics[0] = pl + vl + el; P.metrics[1] = pl; P.metrics[2] = vl; P.metrics[3] = el;
+  }
+}

@@ -42,9 +42,14 @@ class RREnvIO(C.Structure):
                 ("terminate_when_unhealthy", C.c_int32)]
 
 
+class RRPpoCfg(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("entropy_cost", "discounting", "reward_scaling", "gae_lambda", "clipping_epsilon", "min_std")] + \
+        [("normalize_advantage", C.c_int32)]
+
+
 EXPORTS = ["rr_model_load", "rr_model_dims", "rr_model_set_solver", "rr_model_set_solver_type", "rr_model_destroy", "rr_model_table", "rr_kernarg_layout", "rr_batch_create",
            "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset", "rr_pipeline_step_to", "rr_env_step_to",
-           "rr_compute_gae", "rr_mlp_forward", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_schedule", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
+           "rr_compute_gae", "rr_mlp_forward", "rr_ppo_loss_workspace_bytes", "rr_ppo_loss", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_schedule", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
 
 _lib = None
 
@@ -81,6 +86,9 @@ def lib():
         L.rr_compute_gae.argtypes = [C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rr_mlp_forward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(RRMlpNet), C.POINTER(RRMlpNet),
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rr_ppo_loss_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
+        L.rr_ppo_loss_workspace_bytes.restype = C.c_size_t
+        L.rr_ppo_loss.argtypes = [C.c_void_p] * 9 + [C.c_int32] * 3 + [C.POINTER(RRPpoCfg)] + [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]
         L.rr_wrap_episode_autoreset.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32)] + \
             [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_void_p]
         L.rr_batch_set_profile.argtypes = [C.c_void_p, C.c_void_p]
@@ -335,3 +343,40 @@ def mlp_forward(obs, mean=None, std=None, policy=None, value=None, want_pre=Fals
                                 _ptr(std, numel=K) if std is not None else None, C.byref(pn) if pn is not None else None,
                                 C.byref(vn) if vn is not None else None, p(pol_out), p(val_out), p(pol_pre), p(val_pre), C.c_void_p(stream)))
     return pol_out, val_out, pol_pre, val_pre
+
+
+def ppo_loss(policy_logits, values, data, idx, noise, T: int, *, entropy_cost, discounting, reward_scaling, gae_lambda, clipping_epsilon,
+             normalize_advantage=True, min_std=0.001, out=None):
+    """Loss half of a PPO minibatch update and its gradient w.r.t. the network outputs (C ABI `rr_ppo_loss`, 3 launches).
+
+    policy_logits [(T+1)*B, 2A] / values [(T+1)*B]: the networks' outputs on the gathered minibatch, time-major; `data`: the
+    collected batch, batch-major (`raw_action` [R, T, A]; `log_prob`, `reward`, `discount`, `truncation` [R, T]); idx [B] int64
+    minibatch rows (None = the first B rows); noise [T*B, A].  Returns (grad_logits, grad_values, metrics[4]); `out` = a dict
+    of persistent buffers {grad_logits, grad_values, metrics, workspace} reused across calls (HIP-graph capture needs that)."""
+    M, P2 = policy_logits.shape
+    B = M // (T + 1)
+    A = P2 // 2
+    dev = policy_logits.device
+    for t in (policy_logits, values, noise, data["raw_action"], data["log_prob"], data["reward"], data["discount"], data["truncation"]):
+        _ptr(t)
+    if values.numel() != M or noise.numel() != T * B * A or data["raw_action"].shape[1:] != (T, A) or data["log_prob"].shape[1] != T:
+        raise ValueError("rr_ppo_loss: inconsistent shapes")
+    if idx is not None:
+        _ptr(idx, torch.int64, B)
+    elif data["log_prob"].shape[0] < B:
+        raise ValueError("rr_ppo_loss: fewer batch rows than the minibatch")
+    out = out if out is not None else {}
+    wb = lib().rr_ppo_loss_workspace_bytes(T, B)
+    if "workspace" not in out or out["workspace"].numel() * 8 < wb or out["grad_logits"].shape != policy_logits.shape:
+        out["workspace"] = torch.empty((wb + 7) // 8, dtype=torch.float64, device=dev)
+        out["grad_logits"] = torch.empty_like(policy_logits)
+        out["grad_values"] = torch.empty(M, device=dev)
+        out["metrics"] = torch.empty(4, device=dev)
+    cfg = RRPpoCfg(entropy_cost, discounting, reward_scaling, gae_lambda, clipping_epsilon, min_std, 1 if normalize_advantage else 0)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _check(lib().rr_ppo_loss(policy_logits.data_ptr(), values.data_ptr(), data["raw_action"].data_ptr(), data["log_prob"].data_ptr(),
+                             data["reward"].data_ptr(), data["discount"].data_ptr(), data["truncation"].data_ptr(),
+                             idx.data_ptr() if idx is not None else None, noise.data_ptr(), T, B, A, C.byref(cfg),
+                             out["grad_logits"].data_ptr(), out["grad_values"].data_ptr(), out["metrics"].data_ptr(),
+                             out["workspace"].data_ptr(), out["workspace"].numel() * 8, C.c_void_p(stream)))
+    return out["grad_logits"], out["grad_values"], out["metrics"]

@@ -170,7 +170,19 @@ def train(
     use_fused = (device.type == "cuda" and os.environ.get("RR_FUSED_MLP", "1") == "1"
                  and fused_mlp.fusable(policy_net, fused_mlp.POLICY_HIDDEN, 64) and fused_mlp.fusable(value_net, fused_mlp.VALUE_HIDDEN, 1))
 
+    # ... and the loss half + backward without an autograd graph (`fused_update`: rr_ppo_loss, gradients written straight into the
+    # flat buffer).  RR_FUSED_LOSS=0 keeps compute_ppo_loss + loss.backward() on the fused forward.
+    fused_update_fn = None
+    if use_fused and os.environ.get("RR_FUSED_LOSS", "1") == "1" and not (global_advantage_normalization and process_count > 1):
+        from . import fused_update
+        fused_update_fn = fused_update.FusedUpdate(policy_net, value_net, dist, T, entropy_cost=entropy_cost, discounting=discounting,
+                                                   reward_scaling=reward_scaling, gae_lambda=gae_lambda, clipping_epsilon=clipping_epsilon,
+                                                   normalize_advantage=normalize_advantage)
+
     def fwd_bwd(data, idx, nparams):
+        if fused_update_fn is not None:
+            mean, std = (nparams.mean, nparams.std) if normalize_observations else (None, None)
+            return fused_update_fn(data, idx, mean, std, gen)
         mbd = {k: data[k][idx].transpose(0, 1) for k in ("raw_action", "log_prob", "reward", "discount", "truncation")}
         if use_fused:
             raw = data["obs"][idx].transpose(0, 1)                         # [T+1, B, obs], time-major gather

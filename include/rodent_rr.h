@@ -157,6 +157,26 @@ typedef struct rr_mlp_net {
 int rr_mlp_forward(const float* obs, int32_t M, int32_t K, const float* mean, const float* std, const rr_mlp_net* policy,
                    const rr_mlp_net* value, float* policy_out, float* value_out, float* policy_pre, float* value_pre, void* stream);
 
+/* The loss half of `brax.training.agents.ppo.losses.compute_ppo_loss` [UP; REF
+ * brax_rodent_run_ppo.py:97-114] and its gradient with respect to the network outputs, in three launches without atomics
+ * (csrc/rr_ppo.h): truncation-aware GAE, device-local advantage normalisation (population std + 1e-8), tanh-normal log-prob
+ * (scale = softplus + min_std), clipped surrogate, value loss 0.25 mean((vs - v)^2), entropy estimated with one normal draw
+ * per action dimension.  Inputs (device float32): policy_logits [(T+1)*B][2A] and values [(T+1)*B], the networks' outputs on
+ * the gathered minibatch, TIME-major (row t*B + b; rows T*B.. belong to the bootstrap observation); the batch leaves
+ * raw_action [R][T][A], log_prob / reward / discount / truncation [R][T] batch-major as collected, addressed through idx [B]
+ * (int64 rows of the minibatch; NULL = rows 0..B-1); noise [T*B][A] standard normal draws.  Outputs: grad_logits
+ * [(T+1)*B][2A] and grad_values [(T+1)*B] (d total_loss / d output; bootstrap rows zero), metrics[4] = total_loss,
+ * policy_loss, v_loss, entropy_loss.  workspace: rr_ppo_loss_workspace_bytes(T, B) bytes of device memory, 8-byte aligned. */
+typedef struct rr_ppo_cfg {
+  float entropy_cost, discounting, reward_scaling, gae_lambda, clipping_epsilon, min_std;
+  int32_t normalize_advantage;
+} rr_ppo_cfg;
+size_t rr_ppo_loss_workspace_bytes(int32_t T, int32_t B);
+int rr_ppo_loss(const float* policy_logits, const float* values, const float* raw_action, const float* log_prob, const float* reward,
+                const float* discount, const float* truncation, const int64_t* idx, const float* noise, int32_t T, int32_t B, int32_t A,
+                const rr_ppo_cfg* cfg, float* grad_logits, float* grad_values, float* metrics, void* workspace, size_t workspace_bytes,
+                void* stream);
+
 /* brax.envs.wrappers.training.EpisodeWrapper + AutoResetWrapper [UP; SURVEY.md 3.4] after an env step, in one launch:
  * steps' = (prev_done ? 0 : prev_steps) + action_repeat; over = steps' >= episode_length; done <- over ? 1 : done;
  * truncation = over ? 1 - done_env : 0; and for every env with done != 0 the rows of the `narr` (<= 12) arrays `cur[i]`

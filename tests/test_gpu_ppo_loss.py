@@ -1,0 +1,114 @@
+"""GPU: the fused PPO loss + output-gradient kernels (C ABI `rr_ppo_loss`) and the autograd-free minibatch update built on
+them, against `losses.compute_ppo_loss` + autograd in float32 (the path they replace) and in float64 (the yardstick)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+CFG = dict(entropy_cost=1e-3, discounting=0.97, reward_scaling=1.0, gae_lambda=0.95, clipping_epsilon=0.3)
+
+
+def _fixed_noise_dist(A, noise):
+    from rodent_amd.training.networks import NormalTanhDistribution
+
+    class FixedNoise(NormalTanhDistribution):
+        def sample_no_postprocessing(self, logits, generator=None):
+            loc, scale = self._params(logits)
+            return loc + scale * noise.to(loc.dtype).to(loc.device).reshape(loc.shape)
+    return FixedNoise(A)
+
+
+def _batch(T, B, R, A, seed):
+    g = torch.Generator().manual_seed(seed)
+    data = dict(raw_action=torch.randn(R, T, A, generator=g) * 0.8, log_prob=torch.randn(R, T, generator=g) * 2 - 25,
+                reward=torch.rand(R, T, generator=g), truncation=(torch.rand(R, T, generator=g) < 0.05).float())
+    data["discount"] = 1 - (torch.rand(R, T, generator=g) < 0.1).float()
+    logits = torch.randn((T + 1) * B, 2 * A, generator=g) * 0.7
+    values = torch.randn((T + 1) * B, generator=g) * 3
+    noise = torch.randn(T * B, A, generator=g)
+    idx = torch.randperm(R, generator=g)[:B]
+    return data, logits, values, noise, idx
+
+
+def _reference(data, logits, values, noise, idx, T, B, A, dtype, device, normalize_advantage=True):
+    """compute_ppo_loss + autograd in `dtype`; returns (metrics, d loss / d logits, d loss / d values)."""
+    from rodent_amd.training.agents.ppo import losses
+    c = lambda x: x.to(dtype).to(device)
+    lg = c(logits).clone().requires_grad_(True)
+    vl = c(values).clone().requires_grad_(True)
+    rows = idx if idx is not None else torch.arange(B)
+    mbd = {k: c(data[k][rows]).transpose(0, 1) for k in ("raw_action", "log_prob", "reward", "discount", "truncation")}
+    v = vl.reshape(T + 1, B)
+    loss, m = losses.compute_ppo_loss(lg[:T * B].reshape(T, B, 2 * A), v[:T], v[T], mbd, _fixed_noise_dist(A, noise),
+                                      normalize_advantage=normalize_advantage, **CFG)
+    loss.backward()
+    return torch.stack([m[k] for k in ("total_loss", "policy_loss", "v_loss", "entropy_loss")]).double().cpu(), \
+        lg.grad.double().cpu(), vl.grad.double().cpu()
+
+
+@pytest.mark.parametrize("T,B,R,A,use_idx,norm", [(10, 256, 700, 30, True, True), (10, 2048, 2048, 30, True, True), (5, 77, 77, 30, False, True),
+                                                  (7, 130, 200, 45, True, False), (3, 8, 8, 2, False, True)])
+def test_fused_loss_and_output_gradients(T, B, R, A, use_idx, norm):
+    from rodent_amd import hip
+    data, logits, values, noise, idx = _batch(T, B, R, A, seed=T * 1000 + B)
+    if not use_idx:
+        idx = None
+    m64, gl64, gv64 = _reference(data, logits, values, noise, idx, T, B, A, torch.float64, "cpu", norm)
+    m32, gl32, gv32 = _reference(data, logits, values, noise, idx, T, B, A, torch.float32, DEV, norm)
+    dd = {k: v.to(DEV).contiguous() for k, v in data.items()}
+    gl, gv, m = hip.ppo_loss(logits.to(DEV), values.to(DEV), dd, idx.to(DEV) if idx is not None else None, noise.to(DEV), T,
+                             normalize_advantage=norm, **CFG)
+    torch.cuda.synchronize()
+    gl, gv, m = gl.double().cpu(), gv.double().cpu(), m.double().cpu()
+    assert torch.isfinite(gl).all() and torch.isfinite(gv).all()
+    assert (gl[T * B:] == 0).all() and (gv[T * B:] == 0).all()                 # bootstrap rows
+    for name, got, t32, want in (("logits", gl, gl32, gl64), ("values", gv, gv32, gv64), ("metrics", m, m32, m64)):
+        scale = want.abs().max()
+        err, err32 = (got - want).abs().max() / scale, (t32 - want).abs().max() / scale
+        print(f"T={T} B={B} A={A} {name}: fused {err:.2e}  torch-f32 {err32:.2e}  (relative to max |.|)")
+        assert err <= 3 * err32 + 2e-6, (name, float(err), float(err32))        # in the float32 class of the path it replaces
+    # every sample is either inside the clip range (tie of the two surrogates) or outside: both branches are exercised
+    assert (gl64[:T * B].abs().sum(1) > 0).all()
+
+
+def test_fused_update_equals_the_autograd_path():
+    """FusedUpdate fills the flat gradient buffer with what compute_ppo_loss + backward (on the same fused forward) produce."""
+    from rodent_amd.training import distributed as D, fused_mlp, networks
+    from rodent_amd.training.agents.ppo import fused_update, losses
+    torch.manual_seed(0)
+    T, B, R, K, A = 6, 96, 300, 211, 30
+    nets = networks.make_ppo_networks(K, A, device=DEV)
+    pnet, vnet, dist = nets.policy_network, nets.value_network, nets.parametric_action_distribution
+    params = list(pnet.parameters()) + list(vnet.parameters())
+    flat = D.FlatGrads(params)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    data, _, _, _, idx = _batch(T, B, R, A, seed=9)
+    data = {k: v.to(DEV).contiguous() for k, v in data.items()}
+    data["obs"] = torch.randn(R, T + 1, K, device=DEV, generator=g) * 2 + 0.5
+    idx = idx.to(DEV)
+    mean, std = torch.randn(K, device=DEV, generator=g) * 0.3, torch.rand(K, device=DEV, generator=g) + 0.5
+    fu = fused_update.FusedUpdate(pnet, vnet, dist, T, normalize_advantage=True, **CFG)
+    gen = torch.Generator(device=DEV).manual_seed(77)
+    m_f = fu(data, idx, mean, std, gen)
+    got = flat.flat.clone()
+    m_f = {k: float(v) for k, v in m_f.items()}
+    # the path it replaces, same noise stream
+    gen = torch.Generator(device=DEV).manual_seed(77)
+    mbd = {k: data[k][idx].transpose(0, 1) for k in ("raw_action", "log_prob", "reward", "discount", "truncation")}
+    raw = data["obs"][idx].transpose(0, 1)
+    logits_all, values_all = fused_mlp.actor_critic(raw.reshape((T + 1) * B, -1), mean, std, pnet, vnet)
+    values = values_all.reshape(T + 1, B)
+    loss, m = losses.compute_ppo_loss(logits_all[:T * B].reshape(T, B, -1), values[:T], values[T], mbd, dist, normalize_advantage=True,
+                                      generator=gen, **CFG)
+    flat.zero_()
+    loss.backward()
+    want = flat.flat.clone()
+    o = 0
+    for p in params:                                           # per tensor: the scales differ by orders of magnitude
+        a, b = got[o:o + p.numel()], want[o:o + p.numel()]
+        o += p.numel()
+        assert torch.isfinite(a).all()
+        assert (a - b).abs().max() <= 2e-4 * b.abs().max() + 1e-9, (tuple(p.shape), float((a - b).abs().max()), float(b.abs().max()))
+    for k in m_f:
+        assert abs(m_f[k] - float(m[k])) <= 1e-5 * max(1.0, abs(float(m[k]))), (k, m_f[k], float(m[k]))
