@@ -462,6 +462,31 @@ extern "C" int rr_ppo_loss(const float* policy_logits, const float* values, cons
   return RR_OK;
 }
 
+// elementwise half of a hidden SiLU layer's backward (csrc/rr_ppo.h)
+static int silu_bwd_blocks(int M, int* rows_per_block) {
+  const int target = 512;                                   // blocks: two per CU
+  *rows_per_block = std::max(8, (M + target - 1) / target);
+  return (M + *rows_per_block - 1) / *rows_per_block;
+}
+extern "C" size_t rr_mlp_silu_backward_workspace_bytes(int32_t M, int32_t H) {
+  if (M <= 0 || H <= 0) return 0;
+  int rpb;
+  return (size_t)silu_bwd_blocks(M, &rpb) * H * sizeof(float);
+}
+extern "C" int rr_mlp_silu_backward(const float* g, const float* z, int32_t M, int32_t H, float* delta, float* h, float* bias_grad,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  if (!g || !z || !delta || !h || !bias_grad || !workspace || M <= 0 || H <= 0) return fail(RR_EINVAL, "rr_mlp_silu_backward: bad argument");
+  if (H > 256 || 256 % H) return fail(RR_EUNSUPPORTED, "rr_mlp_silu_backward: the layer width must divide 256");
+  if (workspace_bytes < rr_mlp_silu_backward_workspace_bytes(M, H)) return fail(RR_EINVAL, "rr_mlp_silu_backward: workspace too small");
+  int rpb;
+  const int nblk = silu_bwd_blocks(M, &rpb);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(rr_silu_bwd_kernel, dim3(nblk), dim3(256), 0, st, g, z, M, H, rpb, delta, h, (float*)workspace);
+  hipLaunchKernelGGL(rr_colsum_kernel, dim3((H + 15) / 16), dim3(256), 0, st, (const float*)workspace, nblk, H, bias_grad);
+  HIPCHK(hipGetLastError());
+  return RR_OK;
+}
+
 // ------------------------------------------------------------------------------------------ PPO: fused MLP forward (MFMA f32)
 static int mlp_net(const rr_mlp_net* n, int K, int hidden, bool is_value, RRMlpNet* out, const char* who) {
   memset(out, 0, sizeof(*out));
@@ -498,6 +523,40 @@ extern "C" int rr_mlp_forward(const float* obs, int32_t M, int32_t K, const floa
     attr_set = true;
   }
   hipLaunchKernelGGL(rr_mlp_forward_kernel, dim3((M + RR_MLP_BM - 1) / RR_MLP_BM), dim3(256), lds, (hipStream_t)stream, A);
+  HIPCHK(hipGetLastError());
+  return RR_OK;
+}
+
+// value network backward: the delta chain on the matrix cores (csrc/rr_mlp.h)
+extern "C" size_t rr_mlp_value_backward_workspace_bytes(int32_t M, int32_t nhidden) {
+  if (M <= 0 || nhidden <= 0) return 0;
+  return (size_t)nhidden * ((M + RR_MLP_BM - 1) / RR_MLP_BM) * RR_MLP_VH * sizeof(float);
+}
+extern "C" int rr_mlp_value_backward(const float* grad_value, const float* head_weight, const float* const* hidden_weights_t, int32_t nhidden,
+                                     int32_t M, float* pre_act, float* delta, float* const* bias_grads, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+  if (!grad_value || !head_weight || !hidden_weights_t || !pre_act || !delta || !bias_grads || !workspace || M <= 0)
+    return fail(RR_EINVAL, "rr_mlp_value_backward: bad argument");
+  if (nhidden < 1 || nhidden > RR_MLP_MAXL) return fail(RR_EUNSUPPORTED, "rr_mlp_value_backward: unsupported number of hidden layers");
+  if (workspace_bytes < rr_mlp_value_backward_workspace_bytes(M, nhidden)) return fail(RR_EINVAL, "rr_mlp_value_backward: workspace too small");
+  RRMlpBwdArgs A;
+  memset(&A, 0, sizeof(A));
+  A.g = grad_value; A.w_head = head_weight; A.z = pre_act; A.delta = delta; A.part = (float*)workspace; A.M = M; A.nh = nhidden;
+  A.nblk = (M + RR_MLP_BM - 1) / RR_MLP_BM;
+  for (int j = 0; j < nhidden; ++j) {
+    if (!bias_grads[j] || (j > 0 && !hidden_weights_t[j])) return fail(RR_EINVAL, "rr_mlp_value_backward: null layer pointer");
+    A.bgrad[j] = bias_grads[j];
+    A.Wt[j] = j > 0 ? hidden_weights_t[j] : nullptr;
+  }
+  const size_t lds = RR_MLP_BWD_LDS_FLOATS * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute((const void*)rr_mlp_value_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(rr_mlp_value_backward_kernel, dim3(A.nblk), dim3(256), lds, st, A);
+  hipLaunchKernelGGL(rr_mlp_colsum_kernel, dim3(RR_MLP_VH / 16, nhidden), dim3(256), 0, st, A);
   HIPCHK(hipGetLastError());
   return RR_OK;
 }

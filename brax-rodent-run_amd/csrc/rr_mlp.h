@@ -253,3 +253,107 @@ __global__ __launch_bounds__(256, 2) void rr_mlp_forward_kernel(const RRMlpArgs 
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------ value network, backward: the delta chain
+// Backward pass of the value MLP's hidden stack on the matrix cores, the mirror image of the forward kernel: one workgroup
+// carries 32 rows from the head back to the first hidden layer,
+//   delta_{nh-1} = g w_head * silu'(z_{nh-1}),     delta_{j-1} = (delta_j W_j) * silu'(z_{j-1}),  j = nh-1 .. 1,
+// with the delta tile resident in LDS between layers (the products delta_j W_j never go to HBM) and the epilogue doing what
+// were separate passes: silu' from the forward's pre-activation dump, h_j = silu(z_j) written over the dump (operand of
+// dW_{j+1} = delta_{j+1}' h_j, left to the caller's matrix products together with dW_0 = delta_0' x), delta_j written out, and
+// the column sums of delta_j (= db_j) as per-workgroup partial sums reduced in fixed order by rr_mlp_colsum_kernel.
+// The B operand of delta_j W_j is W_j read "down the columns"; the caller passes W_j TRANSPOSED ([in][out] row-major), so the
+// weight staging and the k-loop are the forward's (rr_mlp_chunk).
+struct RRMlpBwdArgs {
+  const float* g;                    // [M]  d loss / d value
+  const float* w_head;               // [256]
+  const float* Wt[RR_MLP_MAXL];      // Wt[j], j = 1 .. nh-1: W_j transposed, [256 in][256 out]
+  float* z;                          // [nh][M][256]  pre-activations in, silu(z) out
+  float* delta;                      // [nh][M][256]  out
+  float* part;                       // [nh][gridDim.x][256]
+  float* bgrad[RR_MLP_MAXL];         // db_j [256], j = 0 .. nh-1 (written by rr_mlp_colsum_kernel)
+  int M, nh, nblk;
+};
+
+// acc (or, at the head, g w_head) -> delta: multiply by silu'(z), store delta / silu(z), keep the tile in LDS, column sums
+template <bool HEAD>
+__device__ __forceinline__ void rr_mlp_bwd_epilogue(const RRMlpBwdArgs& A, int j, float* actV, const rr_f16& a0, const rr_f16& a1,
+                                                    const float* gm /* [16] rows of this lane, HEAD only */, int lane, int wv, int row0) {
+  float* zj = A.z + (size_t)j * A.M * RR_MLP_VH;
+  float* dj = A.delta + (size_t)j * A.M * RR_MLP_VH;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int n = 64 * wv + 32 * t + (lane & 31);
+    const float wn = HEAD ? A.w_head[n] : 0.0f;
+    float cs = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      float d = 0.0f;
+      if (row0 + m < A.M) {
+        const size_t i = (size_t)(row0 + m) * RR_MLP_VH + n;
+        const float zz = zj[i], s = 1.0f / (1.0f + expf(-zz));
+        d = (HEAD ? gm[r] * wn : (t ? a1[r] : a0[r])) * (s * (1.0f + zz * (1.0f - s)));
+        dj[i] = d;
+        zj[i] = zz * s;
+      }
+      actV[m * RR_SV + n] = d;
+      cs += d;
+    }
+    cs += __shfl_xor(cs, 32);
+    if (lane < 32) A.part[((size_t)j * A.nblk + blockIdx.x) * RR_MLP_VH + n] = cs;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void rr_mlp_value_backward_kernel(const RRMlpBwdArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* sW = lds;                                   // [256][18]  chunk of W_j transposed
+  float* actV = sW + RR_MLP_VH * RR_SX;              // [32][258]  delta tile
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int row0 = blockIdx.x * RR_MLP_BM;
+  {
+    float gm[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      gm[r] = row0 + m < A.M ? A.g[row0 + m] : 0.0f;
+    }
+    rr_f16 z0 = {0}, z1 = {0};
+    rr_mlp_bwd_epilogue<true>(A, A.nh - 1, actV, z0, z1, gm, lane, wv, row0);
+    __syncthreads();
+  }
+  for (int j = A.nh - 1; j >= 1; --j) {
+    rr_f16 a0 = {0}, a1 = {0};
+    rr_f4 ap = {0, 0, 0, 0};
+    RRStage<RR_MLP_VH> gv;
+    constexpr int nchunk = RR_MLP_VH / RR_MLP_KC;
+    gv.fetch(A.Wt[j], RR_MLP_VH, 0, RR_MLP_VH, 0, RR_MLP_VH);
+    for (int c = 0; c < nchunk; ++c) {
+      gv.commit(sW);
+      __syncthreads();
+      if (c + 1 < nchunk) gv.fetch(A.Wt[j], RR_MLP_VH, 0, RR_MLP_VH, (c + 1) * RR_MLP_KC, RR_MLP_VH);
+      rr_mlp_chunk<true, false>(actV, RR_SV, c * RR_MLP_KC, sW, 0, a0, a1, ap, lane, wv);
+      __syncthreads();
+    }
+    rr_mlp_bwd_epilogue<false>(A, j - 1, actV, a0, a1, nullptr, lane, wv, row0);
+    __syncthreads();
+  }
+}
+constexpr int RR_MLP_BWD_LDS_FLOATS = RR_MLP_VH * RR_SX + RR_MLP_BM * RR_SV;
+
+// db_j[n] = sum over workgroups of part[j][b][n]; grid (16 column groups, nh layers)
+__global__ __launch_bounds__(256) void rr_mlp_colsum_kernel(const RRMlpBwdArgs A) {
+  __shared__ float sh[256];
+  const int j = blockIdx.y, c = threadIdx.x & 15, rg = threadIdx.x >> 4, n = blockIdx.x * 16 + c;
+  const float* part = A.part + (size_t)j * A.nblk * RR_MLP_VH;
+  float t = 0.0f;
+  for (int b = rg; b < A.nblk; b += 16) t += part[(size_t)b * RR_MLP_VH + n];
+  sh[threadIdx.x] = t;
+  __syncthreads();
+  if (rg == 0) {
+    float u = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) u += sh[r * 16 + c];
+    A.bgrad[j][n] = u;
+  }
+}

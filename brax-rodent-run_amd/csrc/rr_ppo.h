@@ -172,3 +172,50 @@ __global__ __launch_bounds__(64) void rr_ppo_metrics_kernel(const RRPpoArgs P) {
     P.metrics[0] = pl + vl + el; P.metrics[1] = pl; P.metrics[2] = vl; P.metrics[3] = el;
   }
 }
+
+// ------------------------------------------------------------------------------------------ backward of a hidden SiLU layer, elementwise part
+// Given G = delta_l W_l (the matrix product, [M][H]) and the layer's pre-activations z [M][H]:
+//   delta_{l-1} = G * silu'(z),  silu'(z) = s (1 + z (1 - s)),  s = sigmoid(z)      (may overwrite G)
+//   h_{l-1}     = silu(z) = z s   (the operand of dW_l = delta_l' h_{l-1}; may overwrite z)
+//   db_{l-1}[n] = sum_m delta_{l-1}[m][n]   (per-block partial sums, then rr_colsum_kernel: fixed order, no atomics)
+// One launch instead of the seven (silu, the five pieces of the composite silu_backward, the bias sum) it replaces.
+// H divides 256; a block owns `rows_per_block` consecutive rows; thread -> column tid % H, row group tid / H.
+__global__ __launch_bounds__(256) void rr_silu_bwd_kernel(const float* __restrict__ G, const float* z, int M, int H, int rows_per_block,
+                                                          float* delta, float* h, float* __restrict__ part /* [gridDim.x][H] */) {
+  __shared__ float sh[256];
+  const int n = threadIdx.x % H, rg = threadIdx.x / H, nrg = 256 / H;
+  const int m0 = blockIdx.x * rows_per_block, m1 = min(M, m0 + rows_per_block);
+  float acc = 0.0f;
+  for (int m = m0 + rg; m < m1; m += nrg) {
+    const size_t i = (size_t)m * H + n;
+    const float zz = z[i], s = 1.0f / (1.0f + expf(-zz));
+    const float d = G[i] * (s * (1.0f + zz * (1.0f - s)));
+    delta[i] = d;
+    h[i] = zz * s;
+    acc += d;
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  if (rg == 0) {
+    float t = acc;
+    for (int r = 1; r < nrg; ++r) t += sh[r * H + n];
+    part[(size_t)blockIdx.x * H + n] = t;
+  }
+}
+// out[n] = sum_b part[b][n]: a block owns 16 columns, 16 row groups of threads each sum every 16th row (64-byte coalesced
+// reads), then the 16 group sums go through LDS in a fixed order
+__global__ __launch_bounds__(256) void rr_colsum_kernel(const float* __restrict__ part, int nblk, int H, float* __restrict__ out) {
+  __shared__ float sh[256];
+  const int c = threadIdx.x & 15, rg = threadIdx.x >> 4, n = blockIdx.x * 16 + c;
+  float t = 0.0f;
+  if (n < H)
+    for (int b = rg; b < nblk; b += 16) t += part[(size_t)b * H + n];
+  sh[threadIdx.x] = t;
+  __syncthreads();
+  if (rg == 0 && n < H) {
+    float u = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) u += sh[r * 16 + c];
+    out[n] = u;
+  }
+}

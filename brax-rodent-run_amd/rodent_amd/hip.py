@@ -49,7 +49,7 @@ class RRPpoCfg(C.Structure):
 
 EXPORTS = ["rr_model_load", "rr_model_dims", "rr_model_set_solver", "rr_model_set_solver_type", "rr_model_destroy", "rr_model_table", "rr_kernarg_layout", "rr_batch_create",
            "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset", "rr_pipeline_step_to", "rr_env_step_to",
-           "rr_compute_gae", "rr_mlp_forward", "rr_ppo_loss_workspace_bytes", "rr_ppo_loss", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_schedule", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
+           "rr_compute_gae", "rr_mlp_forward", "rr_ppo_loss_workspace_bytes", "rr_ppo_loss", "rr_mlp_silu_backward_workspace_bytes", "rr_mlp_silu_backward", "rr_mlp_value_backward_workspace_bytes", "rr_mlp_value_backward", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_schedule", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
 
 _lib = None
 
@@ -89,6 +89,13 @@ def lib():
         L.rr_ppo_loss_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
         L.rr_ppo_loss_workspace_bytes.restype = C.c_size_t
         L.rr_ppo_loss.argtypes = [C.c_void_p] * 9 + [C.c_int32] * 3 + [C.POINTER(RRPpoCfg)] + [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]
+        L.rr_mlp_silu_backward_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
+        L.rr_mlp_silu_backward_workspace_bytes.restype = C.c_size_t
+        L.rr_mlp_silu_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.rr_mlp_value_backward_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
+        L.rr_mlp_value_backward_workspace_bytes.restype = C.c_size_t
+        L.rr_mlp_value_backward.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                            C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t, C.c_void_p]
         L.rr_wrap_episode_autoreset.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32)] + \
             [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_void_p]
         L.rr_batch_set_profile.argtypes = [C.c_void_p, C.c_void_p]
@@ -380,3 +387,48 @@ def ppo_loss(policy_logits, values, data, idx, noise, T: int, *, entropy_cost, d
                              out["grad_logits"].data_ptr(), out["grad_values"].data_ptr(), out["metrics"].data_ptr(),
                              out["workspace"].data_ptr(), out["workspace"].numel() * 8, C.c_void_p(stream)))
     return out["grad_logits"], out["grad_values"], out["metrics"]
+
+
+_silu_ws = {}
+
+
+def mlp_silu_backward(g, z, bias_grad):
+    """delta = g * silu'(z) written over `g`, h = silu(z) written over `z`, bias_grad[n] = column sums of delta (C ABI
+    `rr_mlp_silu_backward`).  g, z: [M, H] contiguous float32 device tensors.  Returns (delta, h) = (g, z)."""
+    M, H = g.shape
+    _ptr(g); _ptr(z, numel=M * H); _ptr(bias_grad, numel=H)
+    wb = lib().rr_mlp_silu_backward_workspace_bytes(M, H)
+    key = (g.device, M, H)
+    if key not in _silu_ws:
+        _silu_ws[key] = torch.empty((wb + 3) // 4, device=g.device)
+    ws = _silu_ws[key]
+    _check(lib().rr_mlp_silu_backward(g.data_ptr(), z.data_ptr(), M, H, g.data_ptr(), z.data_ptr(), bias_grad.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+                                      C.c_void_p(torch.cuda.current_stream(g.device).cuda_stream)))
+    return g, z
+
+
+def mlp_value_backward(grad_value, head_weight, hidden_weights_t, pre_act, bias_grads, bufs=None):
+    """Delta chain of the value network's hidden stack on the matrix cores (C ABI `rr_mlp_value_backward`).
+
+    grad_value [M]; head_weight [1, 256] or [256]; hidden_weights_t: list, entry j >= 1 = W_j.t().contiguous() (entry 0 ignored);
+    pre_act [nh, M, 256] (rr_mlp_forward's value_pre; overwritten by silu(z)); bias_grads: list of nh [256] tensors (written).
+    Returns (delta [nh, M, 256], h = pre_act)."""
+    nh, M, H = pre_act.shape
+    if H != 256 or len(bias_grads) != nh or len(hidden_weights_t) != nh:
+        raise ValueError("rr_mlp_value_backward: inconsistent shapes")
+    _ptr(grad_value, numel=M); _ptr(head_weight, numel=256); _ptr(pre_act)
+    for j in range(nh):
+        _ptr(bias_grads[j], numel=256)
+        if j > 0:
+            _ptr(hidden_weights_t[j], numel=256 * 256)
+    bufs = bufs if bufs is not None else {}
+    wb = lib().rr_mlp_value_backward_workspace_bytes(M, nh)
+    if bufs.get("vb_key") != (M, nh):
+        bufs["vb_ws"] = torch.empty((wb + 3) // 4, device=pre_act.device)
+        bufs["vb_delta"] = torch.empty_like(pre_act)
+        bufs["vb_key"] = (M, nh)
+    wt = (C.c_void_p * nh)(*[hidden_weights_t[j].data_ptr() if j > 0 else None for j in range(nh)])
+    bg = (C.c_void_p * nh)(*[b.data_ptr() for b in bias_grads])
+    _check(lib().rr_mlp_value_backward(grad_value.data_ptr(), head_weight.data_ptr(), wt, nh, M, pre_act.data_ptr(), bufs["vb_delta"].data_ptr(), bg,
+                                       bufs["vb_ws"].data_ptr(), bufs["vb_ws"].numel() * 4, C.c_void_p(torch.cuda.current_stream(pre_act.device).cuda_stream)))
+    return bufs["vb_delta"], pre_act

@@ -18,6 +18,31 @@ from .... import hip
 from ... import fused_mlp
 
 
+_SPLITS = {}
+
+
+def _split(M: int, o: int, i: int) -> int:
+    """Number of row slices for dW = a' b with a [M, o], b [M, i]: the output is small (o, i <= 1263) and the reduction long
+    (M ~ 2e4), so one product fills 1 .. 40 workgroups of a 256-CU GPU; S independent slices give S times as many."""
+    key = (M, o, i)
+    if key not in _SPLITS:
+        tiles = -(-o // 64) * -(-i // 64)
+        want = max(1, 768 // tiles)
+        _SPLITS[key] = max([s for s in range(1, min(want, M // 128) + 1) if M % s == 0], default=1)
+    return _SPLITS[key]
+
+
+def tn_matmul(a, b, out):
+    """out = a' b (weight gradient delta' h) as a batched product over row slices + a fixed-order sum of the partial products."""
+    M, o = a.shape
+    i = b.shape[1]
+    S = _split(M, o, i) if a.is_contiguous() and b.is_contiguous() else 1
+    if S == 1:
+        return torch.mm(a.t(), b, out=out)
+    part = torch.bmm(a.view(S, M // S, o).transpose(1, 2), b.view(S, M // S, i))
+    return torch.sum(part, 0, out=out)
+
+
 class FusedUpdate:
     def __init__(self, policy_net, value_net, dist, unroll_length: int, *, entropy_cost, discounting, reward_scaling, gae_lambda,
                  clipping_epsilon, normalize_advantage):
@@ -33,17 +58,35 @@ class FusedUpdate:
 
     @staticmethod
     def _backward_into_grads(layers, pre, delta, obs, mean, std):
-        """dW_l = delta_l' h_{l-1}, db_l = sum delta_l, delta_{l-1} = (delta_l W_l) * silu'(z_{l-1}), written into `.grad`."""
-        for l in range(len(layers) - 1, -1, -1):
-            W, b = layers[l].weight, layers[l].bias
-            torch.sum(delta, 0, out=b.grad)
-            if l == 0:
-                torch.mm(delta.t(), obs, out=W.grad)
-                if mean is not None:         # the kernel normalised on the fly: dW_1 = (delta' obs - (sum delta) mean') / std
-                    W.grad.addr_(b.grad, mean, alpha=-1.0).div_(std)
-            else:
-                torch.mm(delta.t(), F.silu(pre[l - 1]), out=W.grad)
-                delta = torch.ops.aten.silu_backward(delta @ W, pre[l - 1])
+        """dW_l = delta_l' h_{l-1}, db_l = sum delta_l, delta_{l-1} = (delta_l W_l) * silu'(z_{l-1}), written into `.grad`.
+        `pre` (the forward's pre-activation dumps) is consumed: each z is overwritten by silu(z)."""
+        torch.sum(delta, 0, out=layers[-1].bias.grad)
+        for l in range(len(layers) - 1, 0, -1):
+            W = layers[l].weight
+            # one launch: delta_{l-1} over the product, h_{l-1} over z_{l-1}, db_{l-1}
+            nxt, h = hip.mlp_silu_backward(delta @ W, pre[l - 1], layers[l - 1].bias.grad)
+            tn_matmul(delta, h, W.grad)
+            delta = nxt
+        W = layers[0].weight
+        tn_matmul(delta, obs, W.grad)
+        if mean is not None:                 # the kernel normalised on the fly: dW_1 = (delta' obs - (sum delta) mean') / std
+            W.grad.addr_(layers[0].bias.grad, mean, alpha=-1.0).div_(std)
+
+    def _value_backward_into_grads(self, pre, g, obs, mean, std):
+        """Value network: the delta chain (dX products, silu', h = silu(z), bias gradients) is ONE matrix-core launch
+        (`rr_mlp_value_backward`); the weight gradients are matrix products of its outputs."""
+        layers = self.value_net.layers
+        nh = len(layers) - 1
+        wt = [None] + [layers[j].weight.t().contiguous() for j in range(1, nh)]
+        delta, h = hip.mlp_value_backward(g, layers[nh].weight, wt, pre, [layers[j].bias.grad for j in range(nh)], self.bufs)
+        torch.sum(g, 0, keepdim=True, out=layers[nh].bias.grad)
+        torch.mm(g.unsqueeze(0), h[nh - 1], out=layers[nh].weight.grad)
+        for j in range(nh - 1, 0, -1):
+            tn_matmul(delta[j], h[j - 1], layers[j].weight.grad)
+        W = layers[0].weight
+        tn_matmul(delta[0], obs, W.grad)
+        if mean is not None:
+            W.grad.addr_(layers[0].bias.grad, mean, alpha=-1.0).div_(std)
 
     @torch.no_grad()
     def __call__(self, data, idx, mean, std, generator=None):
@@ -60,5 +103,5 @@ class FusedUpdate:
         g_pol, g_val, metrics = hip.ppo_loss(pol, val, data, idx, noise, T, out=self.bufs, **self.cfg)
         n = T * B                                                                           # the bootstrap rows carry no policy gradient
         self._backward_into_grads(self.policy_net.layers, ppre[:, :n], g_pol[:n], obs[:n], mean, std)
-        self._backward_into_grads(self.value_net.layers, vpre, g_val.unsqueeze(1), obs, mean, std)
+        self._value_backward_into_grads(vpre, g_val, obs, mean, std)
         return {"total_loss": metrics[0], "policy_loss": metrics[1], "v_loss": metrics[2], "entropy_loss": metrics[3]}

@@ -177,6 +177,27 @@ int rr_ppo_loss(const float* policy_logits, const float* values, const float* ra
                 const rr_ppo_cfg* cfg, float* grad_logits, float* grad_values, float* metrics, void* workspace, size_t workspace_bytes,
                 void* stream);
 
+/* Elementwise half of the backward pass of one hidden SiLU layer of the networks above (the matrix products stay with the
+ * caller): with g = delta_l W_l [M][H] and the layer's pre-activations z [M][H] (rr_mlp_forward's dumps),
+ * delta = g * silu'(z), h = silu(z) (the operand of dW_l = delta_l' h) and bias_grad[n] = sum_m delta[m][n], in one pass
+ * (plus a fixed-order column reduction; no atomics).  `delta` may alias `g` and `h` may alias `z`.  H must divide 256.
+ * workspace: rr_mlp_silu_backward_workspace_bytes(M, H) bytes of device memory. */
+size_t rr_mlp_silu_backward_workspace_bytes(int32_t M, int32_t H);
+int rr_mlp_silu_backward(const float* g, const float* z, int32_t M, int32_t H, float* delta, float* h, float* bias_grad,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward pass of the value network's hidden stack (256-wide SiLU layers, as rr_mlp_forward takes them) on the f32 matrix
+ * cores: delta_{nh-1} = g w_head * silu'(z_{nh-1}), delta_{j-1} = (delta_j W_j) * silu'(z_{j-1}) with the delta tile resident in
+ * LDS between layers.  grad_value [M] = d loss / d value; head_weight [256]; hidden_weights_t: HOST array of nhidden device
+ * pointers, entry j (1 <= j < nhidden) = W_j TRANSPOSED ([in][out] row-major), entry 0 unused; pre_act [nhidden][M][256] =
+ * rr_mlp_forward's value_pre, overwritten by silu(z) (the operands h_j of dW_{j+1} = delta_{j+1}' h_j); delta [nhidden][M][256]
+ * out; bias_grads: HOST array of nhidden device pointers, db_j [256] = column sums of delta_j (fixed-order reduction).  The
+ * weight gradients are matrix products of these outputs (dW_0 = delta_0' x) and stay with the caller. */
+size_t rr_mlp_value_backward_workspace_bytes(int32_t M, int32_t nhidden);
+int rr_mlp_value_backward(const float* grad_value, const float* head_weight, const float* const* hidden_weights_t, int32_t nhidden,
+                          int32_t M, float* pre_act, float* delta, float* const* bias_grads, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
 /* brax.envs.wrappers.training.EpisodeWrapper + AutoResetWrapper [UP; SURVEY.md 3.4] after an env step, in one launch:
  * steps' = (prev_done ? 0 : prev_steps) + action_repeat; over = steps' >= episode_length; done <- over ? 1 : done;
  * truncation = over ? 1 - done_env : 0; and for every env with done != 0 the rows of the `narr` (<= 12) arrays `cur[i]`

@@ -112,3 +112,62 @@ def test_fused_update_equals_the_autograd_path():
         assert (a - b).abs().max() <= 2e-4 * b.abs().max() + 1e-9, (tuple(p.shape), float((a - b).abs().max()), float(b.abs().max()))
     for k in m_f:
         assert abs(m_f[k] - float(m[k])) <= 1e-5 * max(1.0, abs(float(m[k]))), (k, m_f[k], float(m[k]))
+
+
+@pytest.mark.parametrize("M,H", [(22528, 256), (20480, 32), (100, 64), (7, 256), (513, 128)])
+def test_silu_backward_elementwise_kernel(M, H):
+    from rodent_amd import hip
+    g = torch.Generator().manual_seed(M + H)
+    G, z = torch.randn(M, H, generator=g), torch.randn(M, H, generator=g) * 3
+    s = torch.sigmoid(z.double())
+    want_d = G.double() * s * (1 + z.double() * (1 - s))
+    want_h, want_b = z.double() * s, want_d.sum(0)
+    Gd, zd, bg = G.to(DEV), z.to(DEV), torch.empty(H, device=DEV)
+    d, h = hip.mlp_silu_backward(Gd, zd, bg)
+    torch.cuda.synchronize()
+    assert d.data_ptr() == Gd.data_ptr() and h.data_ptr() == zd.data_ptr()                  # in place
+    assert (d.double().cpu() - want_d).abs().max() <= 2e-6 * want_d.abs().max()
+    assert (h.double().cpu() - want_h).abs().max() <= 2e-6 * want_h.abs().max()
+    ref32 = (G * torch.sigmoid(z) * (1 + z * (1 - torch.sigmoid(z)))).sum(0).double()       # a float32 column sum's error as the yardstick
+    err, err32 = (bg.double().cpu() - want_b).abs().max(), (ref32 - want_b).abs().max()
+    assert err <= 3 * err32 + 1e-6 * want_b.abs().max(), (float(err), float(err32))
+
+
+@pytest.mark.parametrize("M", [22528, 2048, 45])
+def test_value_backward_chain_kernel(M):
+    """rr_mlp_value_backward against float64: delta_j, h_j = silu(z_j), db_j of every hidden layer; the float32 composition of
+    the same formulas (library products) is the yardstick."""
+    from rodent_amd import hip
+    nh, H = 5, 256
+    g = torch.Generator().manual_seed(M)
+    z = torch.randn(nh, M, H, generator=g) * 1.5
+    Ws = [None] + [torch.randn(H, H, generator=g) / 16 for _ in range(1, nh)]
+    wh = torch.randn(1, H, generator=g) / 16
+    gv = torch.randn(M, generator=g)
+
+    def chain(dt, dev):
+        c = lambda x: x.to(dt).to(dev)
+        zz = c(z)
+        s = torch.sigmoid(zz)
+        sp, hh = s * (1 + zz * (1 - s)), zz * s
+        d = [None] * nh
+        d[nh - 1] = c(gv)[:, None] * c(wh) * sp[nh - 1]
+        for j in range(nh - 1, 0, -1):
+            d[j - 1] = (d[j] @ c(Ws[j])) * sp[j - 1]
+        return torch.stack(d).double().cpu(), hh.double().cpu()
+    d64, h64 = chain(torch.float64, "cpu")
+    d32, _ = chain(torch.float32, DEV)
+    pre = z.to(DEV).contiguous()
+    bgs = [torch.empty(H, device=DEV) for _ in range(nh)]
+    wt = [None] + [Ws[j].to(DEV).t().contiguous() for j in range(1, nh)]
+    delta, h = hip.mlp_value_backward(gv.to(DEV), wh.to(DEV), wt, pre, bgs)
+    torch.cuda.synchronize()
+    assert h.data_ptr() == pre.data_ptr()
+    assert (h.double().cpu() - h64).abs().max() <= 2e-6 * h64.abs().max()
+    for j in range(nh):
+        scale = d64[j].abs().max()
+        err, err32 = (delta[j].double().cpu() - d64[j]).abs().max() / scale, (d32[j] - d64[j]).abs().max() / scale
+        print(f"M={M} layer {j}: mfma chain {err:.2e}  torch-f32 {err32:.2e}")
+        assert err <= 3 * err32 + 2e-6, (j, float(err), float(err32))
+        want_b = d64[j].sum(0)
+        assert (bgs[j].double().cpu() - want_b).abs().max() <= 3e-5 * d64[j].abs().sum(0).max(), j
