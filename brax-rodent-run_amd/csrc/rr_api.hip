@@ -505,7 +505,7 @@ static int mlp_net(const rr_mlp_net* n, int K, int hidden, bool is_value, RRMlpN
   return RR_OK;
 }
 
-extern "C" int rr_mlp_forward(const float* obs, int32_t M, int32_t K, const float* mean, const float* std_, const rr_mlp_net* policy,
+extern "C" int rr_mlp_forward(const float* obs, const int64_t* obs_rows, int32_t M, int32_t K, const float* mean, const float* std_, const rr_mlp_net* policy,
                               const rr_mlp_net* value, float* policy_out, float* value_out, float* policy_pre, float* value_pre, void* stream) {
   if (!obs || M <= 0 || K <= 0 || (!policy && !value)) return fail(RR_EINVAL, "rr_mlp_forward: bad argument");
   if ((mean == nullptr) != (std_ == nullptr)) return fail(RR_EINVAL, "rr_mlp_forward: mean and std must be given together");
@@ -514,7 +514,7 @@ extern "C" int rr_mlp_forward(const float* obs, int32_t M, int32_t K, const floa
   memset(&A, 0, sizeof(A));
   int rc;
   if ((rc = mlp_net(policy, K, RR_MLP_PH, false, &A.pol, "policy")) || (rc = mlp_net(value, K, RR_MLP_VH, true, &A.val, "value"))) return rc;
-  A.obs = obs; A.M = M; A.K = K; A.mean = mean; A.std_ = std_;
+  A.obs = obs; A.rows = obs_rows; A.M = M; A.K = K; A.mean = mean; A.std_ = std_;
   A.pol_out = policy_out; A.val_out = value_out; A.pol_act = policy ? policy_pre : nullptr; A.val_act = value ? value_pre : nullptr;
   const size_t lds = RR_MLP_LDS_FLOATS * sizeof(float);
   static bool attr_set = false;
@@ -557,6 +557,60 @@ extern "C" int rr_mlp_value_backward(const float* grad_value, const float* head_
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(rr_mlp_value_backward_kernel, dim3(A.nblk), dim3(256), lds, st, A);
   hipLaunchKernelGGL(rr_mlp_colsum_kernel, dim3(RR_MLP_VH / 16, nhidden), dim3(256), 0, st, A);
+  HIPCHK(hipGetLastError());
+  return RR_OK;
+}
+
+// weight gradient dW = delta' h as a split-row matrix-core product (csrc/rr_mlp.h)
+struct DwPlan { int to, ti, kc, rows_per_slice, nslice; };
+static DwPlan dw_plan(int M, int O, int I) {
+  DwPlan p;
+  p.to = O <= 32 ? 32 : (O <= 64 ? 64 : 128);
+  p.ti = O <= 32 ? 128 : (O <= 64 ? 64 : 128);
+  p.kc = O <= 32 ? 64 : (O <= 64 ? 32 : 16);             // equal matrix-core work per LDS hand-off in the three tile shapes
+  const int tiles = ((O + p.to - 1) / p.to) * ((I + p.ti - 1) / p.ti);
+  const int want = std::max(1, std::min(512 / tiles, M / (2 * p.kc)));
+  p.rows_per_slice = ((M + want - 1) / want + p.kc - 1) / p.kc * p.kc;
+  p.nslice = (M + p.rows_per_slice - 1) / p.rows_per_slice;
+  return p;
+}
+extern "C" size_t rr_mlp_weight_grad_workspace_bytes(int32_t M, int32_t O, int32_t I) {
+  if (M <= 0 || O <= 0 || I <= 0) return 0;
+  return (size_t)dw_plan(M, O, I).nslice * O * I * sizeof(float);
+}
+template <int GO, int GI, int WO, int WI, int KC>
+static int dw_launch(const RRDwArgs& A, dim3 grid, hipStream_t st) {
+  constexpr int TO = GO * WO * 32, TI = GI * WI * 32;
+  constexpr size_t lds = (size_t)KC * ((TO + (TO % 64 == 0 ? 32 : 0)) + (TI + (TI % 64 == 0 ? 32 : 0))) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute((const void*)rr_mlp_dw_kernel<GO, GI, WO, WI, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((rr_mlp_dw_kernel<GO, GI, WO, WI, KC>), grid, dim3(256), lds, st, A);
+  return RR_OK;
+}
+extern "C" int rr_mlp_weight_grad(const float* delta, const float* act, const int64_t* act_rows, const float* mean, const float* std_,
+                                  const float* delta_colsum, int32_t M, int32_t O, int32_t I, float* grad, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+  if (!delta || !act || !grad || !workspace || M <= 0 || O <= 0 || I <= 0) return fail(RR_EINVAL, "rr_mlp_weight_grad: bad argument");
+  if ((mean == nullptr) != (std_ == nullptr) || (mean && !delta_colsum))
+    return fail(RR_EINVAL, "rr_mlp_weight_grad: mean, std and delta_colsum must be given together");
+  if (workspace_bytes < rr_mlp_weight_grad_workspace_bytes(M, O, I)) return fail(RR_EINVAL, "rr_mlp_weight_grad: workspace too small (rr_mlp_weight_grad_workspace_bytes)");
+  const DwPlan p = dw_plan(M, O, I);
+  RRDwArgs A;
+  memset(&A, 0, sizeof(A));
+  A.rows_per_slice = p.rows_per_slice; A.nslice = p.nslice;
+  A.a = delta; A.b = act; A.rows = act_rows; A.mean = mean; A.std_ = std_; A.bsum = delta_colsum; A.M = M; A.O = O; A.I = I;
+  A.part = (float*)workspace; A.out = grad;
+  const dim3 grid(((O + p.to - 1) / p.to) * ((I + p.ti - 1) / p.ti), A.nslice);
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (p.to == 32) rc = dw_launch<1, 4, 1, 1, 64>(A, grid, st);
+  else if (p.to == 64) rc = dw_launch<2, 2, 1, 1, 32>(A, grid, st);
+  else rc = dw_launch<2, 2, 2, 2, 16>(A, grid, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(rr_mlp_dw_reduce_kernel, dim3((unsigned)(((size_t)O * I + 15) / 16)), dim3(256), 0, st, A);
   HIPCHK(hipGetLastError());
   return RR_OK;
 }

@@ -34,6 +34,7 @@ struct RRMlpNet {
 };
 struct RRMlpArgs {
   const float* obs; int M, K;
+  const int64_t* rows;                       // nullable: sample m reads row rows[m] of `obs` (a minibatch addressed in place)
   const float* mean; const float* std_;      // nullable: no normalisation
   RRMlpNet pol, val;                         // nlayers == 0: that network is skipped
   float* pol_out;                            // [M][pol.out_dim]
@@ -65,6 +66,15 @@ struct RRStage {
       const int e = threadIdx.x + 256 * i, n = e / RR_MLP_KC, kk = e % RR_MLP_KC;
       const bool ok = e < NROWS * RR_MLP_KC && row0 + n < R && k0 + kk < K;
       r[i] = ok ? src[(size_t)(row0 + n) * ld + k0 + kk] : 0.0f;
+    }
+  }
+  // same, element i of this thread reading from the row that starts at src + off[i] (off < 0: no such row); the offsets are
+  // the same for every chunk (a thread keeps its tile rows), so the caller looks the row indices up once
+  __device__ __forceinline__ void fetch_at(const float* src, const long long (&off)[PER], int k0, int K) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int kk = (threadIdx.x + 256 * i) % RR_MLP_KC;
+      r[i] = (off[i] >= 0 && k0 + kk < K) ? src[off[i] + k0 + kk] : 0.0f;
     }
   }
   __device__ __forceinline__ void commit(float* dst /* [NROWS][RR_SX] */) const {
@@ -150,9 +160,15 @@ __global__ __launch_bounds__(256, 2) void rr_mlp_forward_kernel(const RRMlpArgs 
     RRStage<RR_MLP_VH> gv;
     RRStage<RR_MLP_PH> gp;
     const int nchunk = (K + RR_MLP_KC - 1) / RR_MLP_KC;
+    long long xoff[RRStage<RR_MLP_BM>::PER];       // start of this thread's observation rows (minibatch addressed in place)
+#pragma unroll
+    for (int i = 0; i < RRStage<RR_MLP_BM>::PER; ++i) {
+      const int n = (threadIdx.x + 256 * i) / RR_MLP_KC;
+      xoff[i] = (n < RR_MLP_BM && row0 + n < M) ? (long long)(A.rows ? A.rows[row0 + n] : row0 + n) * K : -1;
+    }
     auto fetch = [&](int c) {
       const int k0 = c * RR_MLP_KC;
-      gx.fetch(A.obs, K, row0, M, k0, K);
+      gx.fetch_at(A.obs, xoff, k0, K);
       if (A.mean) {      // normalise in registers: (x - mean) / std  (running_statistics.normalize)
 #pragma unroll
         for (int i = 0; i < RRStage<RR_MLP_BM>::PER; ++i) {
@@ -355,5 +371,126 @@ __global__ __launch_bounds__(256) void rr_mlp_colsum_kernel(const RRMlpBwdArgs A
 #pragma unroll
     for (int r = 0; r < 16; ++r) u += sh[r * 16 + c];
     A.bgrad[j][n] = u;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ weight gradients: dW = delta' h, split over the rows
+// C[o][i] = sum_m a[m][o] b[row(m)][i] with a = delta [M][O], b = h [M][I] or the raw observations (then b is normalised while
+// it is staged, so dW_0 needs no correction term, and `rows` addresses the minibatch inside the unroll buffer, so no gathered
+// copy of the observations is read here).  The output is small (<= 256 x 1263) and the reduction long (M ~ 2e4): a library
+// product fills 1 .. 40 workgroups of the 1024 the chip wants.  Here the row range is cut into `nslice` slices; workgroup
+// (tile, slice) accumulates its [TO x TI] tile over its rows on v_mfma_f32_32x32x2_f32 (both operands are k-major in memory,
+// so a fragment read is 32 consecutive floats of one staged row: lanes 0..31 row k, lanes 32..63 row k+1, strides = 32 mod 64
+// floats keep the two halves on disjoint banks) and writes a partial tile; rr_mlp_dw_reduce_kernel adds the slices in order.
+struct RRDwArgs {
+  const float* a; const float* b;
+  const int64_t* rows;                       // nullable: b's row of sample m is rows[m]
+  const float* mean; const float* std_;      // nullable: the product is taken with (b - mean[i]) / std[i]: applied to the SUM,
+  const float* bsum;                         //   out = (sum_m a b - bsum[o] mean[i]) / std[i], bsum[o] = sum_m a[m][o]
+  int M, O, I, rows_per_slice, nslice;
+  float* part;                               // [nslice][O][I]
+  float* out;                                // [O][I]
+};
+
+template <int GO, int GI, int WO, int WI, int KC>
+__global__ __launch_bounds__(256, 2) void rr_mlp_dw_kernel(const RRDwArgs A) {
+  static_assert(GO * GI == 4, "four wavefronts");
+  constexpr int TO = GO * WO * 32, TI = GI * WI * 32;
+  constexpr int SA = TO + (TO % 64 == 0 ? 32 : 0), SB = TI + (TI % 64 == 0 ? 32 : 0);
+  constexpr int PA = KC * TO / 256, PB = KC * TI / 256;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* sA = lds;                  // [KC][SA]
+  float* sB = lds + KC * SA;        // [KC][SB]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int tiles_i = (A.I + TI - 1) / TI;
+  const int o0 = (blockIdx.x / tiles_i) * TO, i0 = (blockIdx.x % tiles_i) * TI;
+  const int m0 = blockIdx.y * A.rows_per_slice, m1 = min(A.M, m0 + A.rows_per_slice);
+  const int woff = (wv / GI) * WO * 32, ioff = (wv % GI) * WI * 32;
+  rr_f16 acc[WO][WI];
+#pragma unroll
+  for (int x = 0; x < WO; ++x)
+#pragma unroll
+    for (int y = 0; y < WI; ++y) acc[x][y] = rr_f16{0};
+  float ra[PA], rb[PB];
+  long long boff[PB];               // start of b's row of this thread's elements in the NEXT chunk to fetch (-1: past the slice)
+  auto lookup = [&](int mc) {       // one chunk ahead of the loads that use it, so the index load is never on their critical path
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+      const int m = mc + (threadIdx.x + 256 * q) / TI;
+      boff[q] = m < m1 ? (long long)(A.rows ? A.rows[m] : m) * A.I : -1;
+    }
+  };
+  auto fetch = [&](int mc) {
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+      const int e = threadIdx.x + 256 * q, kk = e / TO, oo = e % TO, m = mc + kk;
+      ra[q] = (m < m1 && o0 + oo < A.O) ? A.a[(size_t)m * A.O + o0 + oo] : 0.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+      const int ii = (threadIdx.x + 256 * q) % TI;
+      rb[q] = (boff[q] >= 0 && i0 + ii < A.I) ? A.b[boff[q] + i0 + ii] : 0.0f;
+    }
+  };
+  lookup(m0);
+  fetch(m0);
+  lookup(m0 + KC);
+  for (int mc = m0; mc < m1; mc += KC) {
+#pragma unroll
+    for (int q = 0; q < PA; ++q) { const int e = threadIdx.x + 256 * q; sA[(e / TO) * SA + e % TO] = ra[q]; }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) { const int e = threadIdx.x + 256 * q; sB[(e / TI) * SB + e % TI] = rb[q]; }
+    __syncthreads();
+    if (mc + KC < m1) { fetch(mc + KC); lookup(mc + 2 * KC); }
+    const float* pa = sA + (lane >> 5) * SA + woff + (lane & 31);
+    const float* pb = sB + (lane >> 5) * SB + ioff + (lane & 31);
+#pragma unroll 8
+    for (int k2 = 0; k2 < KC; k2 += 2) {
+      float af[WO], bf[WI];
+#pragma unroll
+      for (int x = 0; x < WO; ++x) af[x] = pa[k2 * SA + 32 * x];
+#pragma unroll
+      for (int y = 0; y < WI; ++y) bf[y] = pb[k2 * SB + 32 * y];
+#pragma unroll
+      for (int x = 0; x < WO; ++x)
+#pragma unroll
+        for (int y = 0; y < WI; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[x], bf[y], acc[x][y], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  float* dst = A.part + (size_t)blockIdx.y * A.O * A.I;
+#pragma unroll
+  for (int x = 0; x < WO; ++x)
+#pragma unroll
+    for (int y = 0; y < WI; ++y) {
+      const int i = i0 + ioff + 32 * y + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = o0 + woff + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (o < A.O && i < A.I) dst[(size_t)o * A.I + i] = acc[x][y][r];
+      }
+    }
+}
+// out[e] = sum_s part[s][e] (then the normaliser, see RRDwArgs): a block owns 16 consecutive outputs, 16 groups of threads each
+// add every 16th slice, the 16 group sums go through LDS in a fixed order
+__global__ __launch_bounds__(256) void rr_mlp_dw_reduce_kernel(const RRDwArgs A) {
+  __shared__ float sh[256];
+  const size_t n = (size_t)A.O * A.I;
+  const int c = threadIdx.x & 15, sg = threadIdx.x >> 4;
+  const size_t e = (size_t)blockIdx.x * 16 + c;
+  float t = 0.0f;
+  if (e < n)
+    for (int s = sg; s < A.nslice; s += 16) t += A.part[(size_t)s * n + e];
+  sh[threadIdx.x] = t;
+  __syncthreads();
+  if (sg == 0 && e < n) {
+    float u = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) u += sh[r * 16 + c];
+    if (A.mean) {
+      const int o = (int)(e / A.I), i = (int)(e % A.I);
+      u = (u - A.bsum[o] * A.mean[i]) / A.std_[i];
+    }
+    A.out[e] = u;
   }
 }

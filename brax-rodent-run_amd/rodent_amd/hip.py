@@ -49,7 +49,7 @@ class RRPpoCfg(C.Structure):
 
 EXPORTS = ["rr_model_load", "rr_model_dims", "rr_model_set_solver", "rr_model_set_solver_type", "rr_model_destroy", "rr_model_table", "rr_kernarg_layout", "rr_batch_create",
            "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset", "rr_pipeline_step_to", "rr_env_step_to",
-           "rr_compute_gae", "rr_mlp_forward", "rr_ppo_loss_workspace_bytes", "rr_ppo_loss", "rr_mlp_silu_backward_workspace_bytes", "rr_mlp_silu_backward", "rr_mlp_value_backward_workspace_bytes", "rr_mlp_value_backward", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_schedule", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
+           "rr_compute_gae", "rr_mlp_forward", "rr_ppo_loss_workspace_bytes", "rr_ppo_loss", "rr_mlp_silu_backward_workspace_bytes", "rr_mlp_silu_backward", "rr_mlp_value_backward_workspace_bytes", "rr_mlp_value_backward", "rr_mlp_weight_grad_workspace_bytes", "rr_mlp_weight_grad", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_schedule", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
 
 _lib = None
 
@@ -84,7 +84,7 @@ def lib():
         L.rr_debug_layout.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_int32)),
                                       C.POINTER(C.POINTER(C.c_int32))]
         L.rr_compute_gae.argtypes = [C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.rr_mlp_forward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(RRMlpNet), C.POINTER(RRMlpNet),
+        L.rr_mlp_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(RRMlpNet), C.POINTER(RRMlpNet),
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rr_ppo_loss_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
         L.rr_ppo_loss_workspace_bytes.restype = C.c_size_t
@@ -96,6 +96,9 @@ def lib():
         L.rr_mlp_value_backward_workspace_bytes.restype = C.c_size_t
         L.rr_mlp_value_backward.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                             C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t, C.c_void_p]
+        L.rr_mlp_weight_grad_workspace_bytes.argtypes = [C.c_int32] * 3
+        L.rr_mlp_weight_grad_workspace_bytes.restype = C.c_size_t
+        L.rr_mlp_weight_grad.argtypes = [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.rr_wrap_episode_autoreset.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32)] + \
             [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_void_p]
         L.rr_batch_set_profile.argtypes = [C.c_void_p, C.c_void_p]
@@ -323,13 +326,17 @@ def _mlp_net(weights, biases):
     return RRMlpNet(C.cast(W, C.POINTER(C.c_void_p)), C.cast(B, C.POINTER(C.c_void_p)), C.cast(S, C.POINTER(C.c_int32)), n), (W, B, S)
 
 
-def mlp_forward(obs, mean=None, std=None, policy=None, value=None, want_pre=False):
+def mlp_forward(obs, mean=None, std=None, policy=None, value=None, want_pre=False, rows=None):
     """Fused normalise + policy MLP + value MLP forward on the f32 matrix cores (C ABI `rr_mlp_forward`).
 
     obs [M, K] float32 device; policy / value: (weights, biases) lists in nn.Linear layout or None.  Returns
-    (policy_out [M, P] | None, value_out [M] | None, policy_pre [L-1, M, 32] | None, value_pre [L-1, M, 256] | None)."""
+    (policy_out [M, P] | None, value_out [M] | None, policy_pre [L-1, M, 32] | None, value_pre [L-1, M, 256] | None).
+    rows (int64 [M], optional): sample m is row rows[m] of obs (the minibatch addressed in place)."""
     M, K = obs.shape
     _ptr(obs)
+    if rows is not None:
+        M = rows.numel()
+        _ptr(rows, torch.int64)
     dev = obs.device
     pn = vn = None
     keep = []
@@ -346,7 +353,7 @@ def mlp_forward(obs, mean=None, std=None, policy=None, value=None, want_pre=Fals
             val_pre = torch.empty(len(value[0]) - 1, M, 256, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     p = lambda t: t.data_ptr() if t is not None else None
-    _check(lib().rr_mlp_forward(obs.data_ptr(), M, K, _ptr(mean, numel=K) if mean is not None else None,
+    _check(lib().rr_mlp_forward(obs.data_ptr(), rows.data_ptr() if rows is not None else None, M, K, _ptr(mean, numel=K) if mean is not None else None,
                                 _ptr(std, numel=K) if std is not None else None, C.byref(pn) if pn is not None else None,
                                 C.byref(vn) if vn is not None else None, p(pol_out), p(val_out), p(pol_pre), p(val_pre), C.c_void_p(stream)))
     return pol_out, val_out, pol_pre, val_pre
@@ -432,3 +439,27 @@ def mlp_value_backward(grad_value, head_weight, hidden_weights_t, pre_act, bias_
     _check(lib().rr_mlp_value_backward(grad_value.data_ptr(), head_weight.data_ptr(), wt, nh, M, pre_act.data_ptr(), bufs["vb_delta"].data_ptr(), bg,
                                        bufs["vb_ws"].data_ptr(), bufs["vb_ws"].numel() * 4, C.c_void_p(torch.cuda.current_stream(pre_act.device).cuda_stream)))
     return bufs["vb_delta"], pre_act
+
+
+_dw_ws = {}
+
+
+def mlp_weight_grad(delta, act, out, rows=None, mean=None, std=None, delta_colsum=None):
+    """out[o, i] = sum_m delta[m, o] * x[m, i] (C ABI `rr_mlp_weight_grad`): x = act[m] or, with `rows`, act[rows[m]]; with
+    mean / std (and delta_colsum [O] = the column sums of delta), x = (act - mean) / std.  delta [M, O], act [R, I],
+    out [O, I]: contiguous float32."""
+    M, O = delta.shape
+    I = act.shape[1]
+    _ptr(delta); _ptr(act); _ptr(out, numel=O * I)
+    if rows is not None:
+        _ptr(rows, torch.int64, M)
+    elif act.shape[0] < M:
+        raise ValueError("rr_mlp_weight_grad: fewer activation rows than delta rows")
+    key = (delta.device, M, O, I)
+    if key not in _dw_ws:
+        _dw_ws[key] = torch.empty((lib().rr_mlp_weight_grad_workspace_bytes(M, O, I) + 3) // 4, device=delta.device)
+    ws = _dw_ws[key]
+    _check(lib().rr_mlp_weight_grad(delta.data_ptr(), act.data_ptr(), rows.data_ptr() if rows is not None else None,
+                                    _ptr(mean, numel=I) if mean is not None else None, _ptr(std, numel=I) if std is not None else None,
+                                    _ptr(delta_colsum, numel=O) if mean is not None else None, M, O, I, out.data_ptr(), ws.data_ptr(), ws.numel() * 4, C.c_void_p(torch.cuda.current_stream(delta.device).cuda_stream)))
+    return out

@@ -1,8 +1,10 @@
 """One PPO minibatch gradient without an autograd graph: the GPU learner's fast path.
 
-gather (time-major, one index_select) -> `rr_mlp_forward` (both networks, one f32-MFMA launch, pre-activations kept) ->
+row indices of the minibatch inside the unroll buffer (no gathered copy of the observations) -> `rr_mlp_forward` (both networks, one f32-MFMA launch, pre-activations kept) ->
 `rr_ppo_loss` (GAE, normalised advantages, surrogate / value / entropy terms AND d loss / d network outputs, three launches) ->
-explicit backward whose matrix products write straight into the flat gradient buffer (`distributed.FlatGrads`).
+explicit backward (`rr_mlp_value_backward`: the value net's delta chain; `rr_mlp_silu_backward` for the 32-wide policy layers;
+`rr_mlp_weight_grad`: every dW as a split-row matrix-core product) writing straight into the flat gradient buffer
+(`distributed.FlatGrads`).
 
 It computes what `losses.compute_ppo_loss` + `loss.backward()` compute [UP brax.training.agents.ppo.losses /
 brax.training.gradients; REF brax_rodent_run_ppo.py:97-114] -- `tests/test_gpu_ppo.py` holds the two paths
@@ -16,31 +18,6 @@ import torch.nn.functional as F
 
 from .... import hip
 from ... import fused_mlp
-
-
-_SPLITS = {}
-
-
-def _split(M: int, o: int, i: int) -> int:
-    """Number of row slices for dW = a' b with a [M, o], b [M, i]: the output is small (o, i <= 1263) and the reduction long
-    (M ~ 2e4), so one product fills 1 .. 40 workgroups of a 256-CU GPU; S independent slices give S times as many."""
-    key = (M, o, i)
-    if key not in _SPLITS:
-        tiles = -(-o // 64) * -(-i // 64)
-        want = max(1, 768 // tiles)
-        _SPLITS[key] = max([s for s in range(1, min(want, M // 128) + 1) if M % s == 0], default=1)
-    return _SPLITS[key]
-
-
-def tn_matmul(a, b, out):
-    """out = a' b (weight gradient delta' h) as a batched product over row slices + a fixed-order sum of the partial products."""
-    M, o = a.shape
-    i = b.shape[1]
-    S = _split(M, o, i) if a.is_contiguous() and b.is_contiguous() else 1
-    if S == 1:
-        return torch.mm(a.t(), b, out=out)
-    part = torch.bmm(a.view(S, M // S, o).transpose(1, 2), b.view(S, M // S, i))
-    return torch.sum(part, 0, out=out)
 
 
 class FusedUpdate:
@@ -57,7 +34,7 @@ class FusedUpdate:
                 p.grad = torch.zeros_like(p)
 
     @staticmethod
-    def _backward_into_grads(layers, pre, delta, obs, mean, std):
+    def _policy_backward_into_grads(layers, pre, delta, obs, rows, mean, std):
         """dW_l = delta_l' h_{l-1}, db_l = sum delta_l, delta_{l-1} = (delta_l W_l) * silu'(z_{l-1}), written into `.grad`.
         `pre` (the forward's pre-activation dumps) is consumed: each z is overwritten by silu(z)."""
         torch.sum(delta, 0, out=layers[-1].bias.grad)
@@ -65,28 +42,22 @@ class FusedUpdate:
             W = layers[l].weight
             # one launch: delta_{l-1} over the product, h_{l-1} over z_{l-1}, db_{l-1}
             nxt, h = hip.mlp_silu_backward(delta @ W, pre[l - 1], layers[l - 1].bias.grad)
-            tn_matmul(delta, h, W.grad)
+            hip.mlp_weight_grad(delta, h, W.grad)
             delta = nxt
-        W = layers[0].weight
-        tn_matmul(delta, obs, W.grad)
-        if mean is not None:                 # the kernel normalised on the fly: dW_1 = (delta' obs - (sum delta) mean') / std
-            W.grad.addr_(layers[0].bias.grad, mean, alpha=-1.0).div_(std)
+        hip.mlp_weight_grad(delta, obs, layers[0].weight.grad, rows=rows, mean=mean, std=std, delta_colsum=layers[0].bias.grad)
 
-    def _value_backward_into_grads(self, pre, g, obs, mean, std):
+    def _value_backward_into_grads(self, pre, g, obs, rows, mean, std):
         """Value network: the delta chain (dX products, silu', h = silu(z), bias gradients) is ONE matrix-core launch
-        (`rr_mlp_value_backward`); the weight gradients are matrix products of its outputs."""
+        (`rr_mlp_value_backward`); the weight gradients are split-row matrix-core products of its outputs."""
         layers = self.value_net.layers
         nh = len(layers) - 1
         wt = [None] + [layers[j].weight.t().contiguous() for j in range(1, nh)]
         delta, h = hip.mlp_value_backward(g, layers[nh].weight, wt, pre, [layers[j].bias.grad for j in range(nh)], self.bufs)
         torch.sum(g, 0, keepdim=True, out=layers[nh].bias.grad)
-        torch.mm(g.unsqueeze(0), h[nh - 1], out=layers[nh].weight.grad)
+        hip.mlp_weight_grad(g.unsqueeze(1), h[nh - 1], layers[nh].weight.grad)
         for j in range(nh - 1, 0, -1):
-            tn_matmul(delta[j], h[j - 1], layers[j].weight.grad)
-        W = layers[0].weight
-        tn_matmul(delta[0], obs, W.grad)
-        if mean is not None:
-            W.grad.addr_(layers[0].bias.grad, mean, alpha=-1.0).div_(std)
+            hip.mlp_weight_grad(delta[j], h[j - 1], layers[j].weight.grad)
+        hip.mlp_weight_grad(delta[0], obs, layers[0].weight.grad, rows=rows, mean=mean, std=std, delta_colsum=layers[0].bias.grad)
 
     @torch.no_grad()
     def __call__(self, data, idx, mean, std, generator=None):
@@ -95,13 +66,14 @@ class FusedUpdate:
         B = idx.numel()
         K = data["obs"].shape[-1]
         A = self.dist.event_size
-        rows = (idx.unsqueeze(0) * (T + 1) + self.trange.unsqueeze(1)).reshape(-1)         # time-major: row t*B + b
-        obs = data["obs"].reshape(-1, K).index_select(0, rows)
+        # the minibatch is addressed inside the unroll buffer: sample (t, b) = row idx[b] * (T + 1) + t, time-major order
+        rows = (idx.unsqueeze(0) * (T + 1) + self.trange.unsqueeze(1)).reshape(-1)
+        obs = data["obs"].reshape(-1, K)
         pol, val, ppre, vpre = hip.mlp_forward(obs, mean, std, fused_mlp.net_params(self.policy_net), fused_mlp.net_params(self.value_net),
-                                               want_pre=True)
+                                               want_pre=True, rows=rows)
         noise = torch.randn(T * B, A, device=obs.device, dtype=obs.dtype, generator=generator)     # the draw of dist.entropy
         g_pol, g_val, metrics = hip.ppo_loss(pol, val, data, idx, noise, T, out=self.bufs, **self.cfg)
         n = T * B                                                                           # the bootstrap rows carry no policy gradient
-        self._backward_into_grads(self.policy_net.layers, ppre[:, :n], g_pol[:n], obs[:n], mean, std)
-        self._value_backward_into_grads(vpre, g_val, obs, mean, std)
+        self._policy_backward_into_grads(self.policy_net.layers, ppre[:, :n], g_pol[:n], obs, rows[:n], mean, std)
+        self._value_backward_into_grads(vpre, g_val, obs, rows, mean, std)
         return {"total_loss": metrics[0], "policy_loss": metrics[1], "v_loss": metrics[2], "entropy_loss": metrics[3]}

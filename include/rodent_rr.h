@@ -144,7 +144,8 @@ int rr_compute_gae(const float* truncation, const float* termination, const floa
  * the `make_ppo_networks` default shapes: policy obs -> 32 x (nlayers-1) -> out (<= 64), value obs -> 256 x (nlayers-1) -> 1,
  * SiLU on hidden layers, float32 throughout.  A network is described by HOST arrays of DEVICE pointers: weights[l] is
  * [sizes[l+1]][sizes[l]] row-major (torch.nn.Linear.weight), biases[l] is [sizes[l+1]]; sizes has nlayers + 1 entries.
- * Either network may be NULL (skipped).  mean / std (device, [K]) may both be NULL (no normalisation), else
+ * Either network may be NULL (skipped).  obs_rows (device int64 [M], nullable): sample m is row obs_rows[m] of `obs` (a minibatch
+ * addressed inside the unroll buffer, no gathered copy).  mean / std (device, [K]) may both be NULL (no normalisation), else
  * x <- (x - mean) / std.  Outputs: policy_out [M][sizes[nlayers]], value_out [M]; optional PRE-activation dumps of the
  * hidden layers (for a backward pass): policy_pre [nlayers-1][M][32], value_pre [nlayers-1][M][256] (NULL = not written).
  * RR_EUNSUPPORTED for other shapes. */
@@ -154,7 +155,7 @@ typedef struct rr_mlp_net {
   const int32_t* sizes;
   int32_t nlayers;
 } rr_mlp_net;
-int rr_mlp_forward(const float* obs, int32_t M, int32_t K, const float* mean, const float* std, const rr_mlp_net* policy,
+int rr_mlp_forward(const float* obs, const int64_t* obs_rows, int32_t M, int32_t K, const float* mean, const float* std, const rr_mlp_net* policy,
                    const rr_mlp_net* value, float* policy_out, float* value_out, float* policy_pre, float* value_pre, void* stream);
 
 /* The loss half of `brax.training.agents.ppo.losses.compute_ppo_loss` [UP; REF
@@ -197,6 +198,18 @@ size_t rr_mlp_value_backward_workspace_bytes(int32_t M, int32_t nhidden);
 int rr_mlp_value_backward(const float* grad_value, const float* head_weight, const float* const* hidden_weights_t, int32_t nhidden,
                           int32_t M, float* pre_act, float* delta, float* const* bias_grads, void* workspace, size_t workspace_bytes,
                           void* stream);
+
+/* Weight gradient of one layer, grad[o][i] = sum_m delta[m][o] * x[m][i], on the f32 matrix cores with the row range split
+ * over workgroups (the output is small, the reduction ~2e4 rows long) and a fixed-order sum of the partial tiles.  delta
+ * [M][O]; act: the layer's input, [M][I] (h = silu(z)) -- or, for the first layer, the RAW observations with act_rows [M]
+ * (int64, nullable) = the row of sample m inside `act` (the minibatch addressed in place, no gathered copy) and mean / std
+ * [I] (nullable, together with delta_colsum [O] = sum_m delta[m][o], the layer's bias gradient) for x = (act - mean) / std,
+ * applied to the sum: grad = (delta' act - delta_colsum mean') / std.  grad [O][I] row-major (torch.nn.Linear.weight.grad).
+ * workspace: rr_mlp_weight_grad_workspace_bytes(M, O, I) bytes of device memory. */
+size_t rr_mlp_weight_grad_workspace_bytes(int32_t M, int32_t O, int32_t I);
+int rr_mlp_weight_grad(const float* delta, const float* act, const int64_t* act_rows, const float* mean, const float* std,
+                       const float* delta_colsum, int32_t M, int32_t O, int32_t I, float* grad, void* workspace, size_t workspace_bytes,
+                       void* stream);
 
 /* brax.envs.wrappers.training.EpisodeWrapper + AutoResetWrapper [UP; SURVEY.md 3.4] after an env step, in one launch:
  * steps' = (prev_done ? 0 : prev_steps) + action_repeat; over = steps' >= episode_length; done <- over ? 1 : done;

@@ -171,3 +171,45 @@ def test_value_backward_chain_kernel(M):
         assert err <= 3 * err32 + 2e-6, (j, float(err), float(err32))
         want_b = d64[j].sum(0)
         assert (bgs[j].double().cpu() - want_b).abs().max() <= 3e-5 * d64[j].abs().sum(0).max(), j
+
+
+@pytest.mark.parametrize("M,O,I,rows,norm", [(22528, 256, 256, False, False), (22528, 256, 1263, True, True), (20480, 32, 32, False, False),
+                                             (20480, 60, 32, False, False), (20480, 32, 1263, True, True), (22528, 1, 256, False, False),
+                                             (45, 256, 256, False, False), (1000, 32, 77, True, False), (131, 60, 32, False, True)])
+def test_weight_grad_kernel(M, O, I, rows, norm):
+    from rodent_amd import hip
+    g = torch.Generator().manual_seed(M + O + I)
+    R = M + 37 if rows else M
+    a, b = torch.randn(M, O, generator=g), torch.randn(R, I, generator=g) * 2 + 0.3
+    ridx = torch.randperm(R, generator=g)[:M] if rows else None
+    mean, std = (torch.randn(I, generator=g) * 0.3, torch.rand(I, generator=g) + 0.5) if norm else (None, None)
+    x = b[ridx] if rows else b
+    if norm:
+        x = (x - mean) / std
+    want = a.double().t() @ x.double()
+    ref32 = (a.to(DEV).t() @ x.to(DEV)).double().cpu()
+    out = torch.empty(O, I, device=DEV)
+    hip.mlp_weight_grad(a.to(DEV), b.to(DEV), out, rows=ridx.to(DEV) if rows else None, mean=mean.to(DEV) if norm else None,
+                        std=std.to(DEV) if norm else None, delta_colsum=a.to(DEV).sum(0) if norm else None)
+    torch.cuda.synchronize()
+    scale = want.abs().max()
+    err, err32 = (out.double().cpu() - want).abs().max() / scale, (ref32 - want).abs().max() / scale
+    print(f"M={M} O={O} I={I}: mfma split-row {err:.2e}  library f32 {err32:.2e}")
+    assert err <= 3 * err32 + 2e-6, (float(err), float(err32))
+
+
+def test_forward_reads_the_minibatch_in_place():
+    """rr_mlp_forward with obs_rows equals the forward on the gathered copy, bit for bit."""
+    from rodent_amd import hip
+    from rodent_amd.training import fused_mlp, networks
+    torch.manual_seed(1)
+    K, A, R, M = 300, 30, 5000, 1000
+    nets = networks.make_ppo_networks(K, A, device=DEV)
+    obs = torch.randn(R, K, device=DEV)
+    rows = torch.randperm(R, device=DEV)[:M]
+    mean, std = torch.randn(K, device=DEV) * 0.1, torch.rand(K, device=DEV) + 0.5
+    pp, vp = fused_mlp.net_params(nets.policy_network), fused_mlp.net_params(nets.value_network)
+    a = hip.mlp_forward(obs, mean, std, pp, vp, want_pre=True, rows=rows)
+    b = hip.mlp_forward(obs[rows].contiguous(), mean, std, pp, vp, want_pre=True)
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and torch.equal(x, y)
