@@ -118,6 +118,9 @@ def parse():
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5), help="BASELINE.json config (2 = the headline metric's)")
     ap.add_argument("--num-envs", type=int, default=None, help="envs per GPU (default 2048; 4096 for config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--substreams", type=int, default=2, help="config 2: the envs of a GPU are stepped as this many sub-batches on separate "
+                    "HIP streams (one sub-batch's slowest envs overlap the others' bulk); 1 = one launch per step")
+    ap.add_argument("--no-graph", action="store_true", help="config 2: issue every step from the host instead of replaying a HIP graph of it")
     ap.add_argument("--solver", default="cg", choices=("cg", "newton"), help="config 2 only; the headline configuration is cg 8/8")
     ap.add_argument("--iterations", type=int, default=8)
     ap.add_argument("--ls-iterations", type=int, default=8)
@@ -204,18 +207,76 @@ def main():
         repeats_ms = [elapsed / len(timed) * 1e3]
     else:
         if args.config == 2:
-            env = envs.get_environment("rodent", track_pos=synthetic_track(), num_envs=N, xml_path=f"{model}.xml", terminate_when_unhealthy=True,
-                                       solver=args.solver, iterations=args.iterations, ls_iterations=args.ls_iterations, device=dev)
-            wenv = wrappers.wrap(env, episode_length=150, action_repeat=1)
+            # The N envs of this GPU are stepped as S sub-batches of N / S envs, each with its own batch, stream, wrapper state and
+            # action generator.  A launch lasts as long as its slowest env (one resident round: 2 waves per SIMD); with S launches in
+            # flight one sub-batch's tail overlaps the others' bulk.  Every env still makes exactly one step per bench step.
+            from rodent_amd.envs import graphed
+            S_ = args.substreams
+            if N % S_:
+                raise SystemExit(f"--substreams {S_} does not divide {N} envs")
+            n_sub = N // S_
             keys = jax_random.split(jax_random.fold_in(jax_random.PRNGKey(0), rank), N)
-            state = wenv.reset(keys)
-            batch, nu = env._batch, env.action_size
+            subs = []
+            for si in range(S_):
+                st = torch.cuda.Stream(dev)
+                with torch.cuda.stream(st):
+                    env = envs.get_environment("rodent", track_pos=synthetic_track(), num_envs=n_sub, xml_path=f"{model}.xml",
+                                               terminate_when_unhealthy=True, solver=args.solver, iterations=args.iterations,
+                                               ls_iterations=args.ls_iterations, device=dev)
+                    wenv = wrappers.wrap(env, episode_length=150, action_repeat=1)
+                    g_ = torch.Generator(device=dev)
+                    g_.manual_seed(1234 + 64 * rank + si)
+                    subs.append(dict(stream=st, env=env, wenv=wenv, gen=g_, state=wenv.reset(keys[si * n_sub:(si + 1) * n_sub])))
+            nu = subs[0]["env"].action_size
 
-            def one_step(state):
-                action = torch.empty(N, nu, device=dev).uniform_(-1.0, 1.0, generator=gen)      # fresh U(-1,1) draws, one launch
-                return wenv.step(state, action)
+            def sub_step(sub, state):
+                action = torch.empty(n_sub, nu, device=dev).uniform_(-1.0, 1.0, generator=sub["gen"])      # fresh U(-1,1) draws, one launch
+                return sub["wenv"].step(state, action)
+
+            def eager_steps(k):
+                for _ in range(k):
+                    for sub in subs:
+                        with torch.cuda.stream(sub["stream"]):
+                            sub["state"] = sub_step(sub, sub["state"])
             workload = (f"{model}.xml random-action rollout, Rodent.step through Episode(150)+AutoReset wrappers, "
-                        f"{args.solver.upper()} {args.iterations}/{args.ls_iterations}, n_frames 10")
+                        f"{args.solver.upper()} {args.iterations}/{args.ls_iterations}, n_frames 10; {S_} sub-batches of {n_sub} envs on {S_} streams, "
+                        + ("host-issued steps" if args.no_graph else "HIP-graph replay of the step"))
+            eager_steps(args.warmup)
+            torch.cuda.synchronize(dev)
+            R_ = 1
+            if not args.no_graph:
+                R_ = max(r for r in range(1, 11) if args.steps % r == 0)            # steps per replay
+                for sub in subs:
+                    sub["graph"] = graphed.GraphedSteps(lambda st_, sub=sub: sub_step(sub, st_), sub["state"], R_, sub["stream"], [sub["gen"]])
+                torch.cuda.synchronize(dev)
+            repeats_ms = []
+            for rep in range(args.repeats):
+                fence()
+                t0 = time.perf_counter()
+                if args.no_graph:
+                    eager_steps(args.steps)
+                else:
+                    for _ in range(args.steps // R_):
+                        for sub in subs:
+                            sub["graph"].replay()
+                fence()
+                repeats_ms.append(max_over_ranks(time.perf_counter() - t0) / args.steps * 1e3)
+            if not args.no_graph:
+                for sub in subs:
+                    sub["state"] = sub["graph"].state
+            assert all(torch.isfinite(sub["state"].obs).all() for sub in subs), "non-finite state in the rollout"
+            # kernel durations by HIP events on each sub-batch's stream: a host-issued pass over the same states (events cannot be
+            # read back from inside a replayed graph); rocprofv3's kernel trace of this command shows the replayed launches themselves
+            for sub in subs:
+                sub["env"]._batch.set_timing(True)
+            eager_steps(args.steps if args.no_graph else min(args.steps, 100))
+            torch.cuda.synchronize(dev)
+            kt = [sub["env"]._batch.kernel_time() for sub in subs]
+            kern_ms, launches = sum(k[0] for k in kt), sum(k[1] for k in kt)
+            batch = subs[0]["env"]._batch
+            total_env_steps = N * world * args.steps
+            elapsed = float(np.median(repeats_ms)) * args.steps * 1e-3
+            extra = {"substreams": S_, "steps_per_graph_replay": None if args.no_graph else R_}
         else:
             # ---- config 5: rodent_pair.xml (two replicated rodents, nv 146, 114 contacts), physics only (pipeline_step)
             from rodent_amd import assets, hip, mjcf
@@ -240,22 +301,22 @@ def main():
                     out[k] = torch.where(bad[:, None], first[k], out[k])
                 return out
             workload = f"{model}.xml physics only (pipeline_step, n_frames 10), random actions, CG 8/8, restart of fallen envs"
-        for _ in range(args.warmup):
-            state = one_step(state)
-        batch.set_timing(True)
-        repeats_ms = []
-        for rep in range(args.repeats):
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(args.warmup):
                 state = one_step(state)
-            fence()
-            repeats_ms.append(max_over_ranks(time.perf_counter() - t0) / args.steps * 1e3)
-        obs = state.obs if args.config == 2 else state["qpos"]
-        assert torch.isfinite(obs).all(), "non-finite state in the rollout"
-        total_env_steps = N * world * args.steps
-        elapsed = float(np.median(repeats_ms)) * args.steps * 1e-3
-    kern_ms, launches = batch.kernel_time()
+            batch.set_timing(True)
+            repeats_ms = []
+            for rep in range(args.repeats):
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    state = one_step(state)
+                fence()
+                repeats_ms.append(max_over_ranks(time.perf_counter() - t0) / args.steps * 1e3)
+            assert torch.isfinite(state["qpos"]).all(), "non-finite state in the rollout"
+            total_env_steps = N * world * args.steps
+            elapsed = float(np.median(repeats_ms)) * args.steps * 1e-3
+    if args.config != 2:
+        kern_ms, launches = batch.kernel_time()
 
     if rank == 0:
         value = total_env_steps / elapsed
@@ -264,10 +325,13 @@ def main():
         # full env step 4(2S + nu + obs + 2) = 7180 B (rodent_optimized); physics only 4(2S + nu) (config 5: 3880 B)
         bytes_per_env_step = 4 * (2 * S + d.nu + (d.obs_dim + 2 if args.config != 5 else 0))
         avg_kernel_s = (kern_ms / max(launches, 1)) * 1e-3
-        achieved = bytes_per_env_step * N / avg_kernel_s / 1e9
+        # config 2: `substreams` launches of N / substreams envs are in flight together, each lasting avg_kernel_s
+        concurrent = extra.get("substreams", 1)
+        achieved = bytes_per_env_step * (N // concurrent) * concurrent / avg_kernel_s / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic() if args.config == 2 else None,
                 "kernel": "rr_step_kernel", "avg_kernel_ms": avg_kernel_s * 1e3, "launches": launches,
+                "envs_per_launch": N // concurrent, "concurrent_launches": concurrent,
                 "algorithmic_bytes_per_env_step": bytes_per_env_step,
                 "limiter": "VALU issue + dependent LDS/L2 latency, not HBM (SURVEY.md 8(d)); see valu_busy_frac"}
         if args.config == 2:

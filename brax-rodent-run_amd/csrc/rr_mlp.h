@@ -110,6 +110,28 @@ __device__ __forceinline__ void rr_mlp_chunk(const float* xa, int sa, int ka, co
   }
 }
 
+// one 256 -> 256 product of the tile in `actV` with W ([256 out][256 in] row-major), the weight chunks through two register stages
+// (chunk c+2 is in flight while chunk c is multiplied).  Ends with a barrier: every wave has read actV when it returns.
+__device__ __forceinline__ void rr_mlp_hidden_layer(const float* W, const float* actV, float* sW, rr_f16& a0, rr_f16& a1, rr_f4& ap, int lane, int wv) {
+  constexpr int nchunk = RR_MLP_VH / RR_MLP_KC;
+  RRStage<RR_MLP_VH> g0, g1;
+  g0.fetch(W, RR_MLP_VH, 0, RR_MLP_VH, 0, RR_MLP_VH);
+  g1.fetch(W, RR_MLP_VH, 0, RR_MLP_VH, RR_MLP_KC, RR_MLP_VH);
+#pragma unroll 1
+  for (int c = 0; c < nchunk; c += 2) {
+    g0.commit(sW);
+    __syncthreads();
+    if (c + 2 < nchunk) g0.fetch(W, RR_MLP_VH, 0, RR_MLP_VH, (c + 2) * RR_MLP_KC, RR_MLP_VH);
+    rr_mlp_chunk<true, false>(actV, RR_SV, c * RR_MLP_KC, sW, 0, a0, a1, ap, lane, wv);
+    __syncthreads();
+    g1.commit(sW);
+    __syncthreads();
+    if (c + 3 < nchunk) g1.fetch(W, RR_MLP_VH, 0, RR_MLP_VH, (c + 3) * RR_MLP_KC, RR_MLP_VH);
+    rr_mlp_chunk<true, false>(actV, RR_SV, (c + 1) * RR_MLP_KC, sW, 0, a0, a1, ap, lane, wv);
+    __syncthreads();
+  }
+}
+
 // epilogue of a 256-wide value layer: act[m][n] = silu(acc + b[n]); C/D map of the 32x32 tile: col = lane & 31,
 // row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 __device__ __forceinline__ void rr_mlp_store_val(float* actV, const rr_f16& a0, const rr_f16& a1, const float* bias, int lane, int wv,
@@ -156,9 +178,10 @@ __global__ __launch_bounds__(256, 2) void rr_mlp_forward_kernel(const RRMlpArgs 
   {
     rr_f16 a0 = {0}, a1 = {0};
     rr_f4 ap = {0, 0, 0, 0};
-    RRStage<RR_MLP_BM> gx;
-    RRStage<RR_MLP_VH> gv;
-    RRStage<RR_MLP_PH> gp;
+    // TWO register stages: the loads of chunk c+2 are issued while chunk c is multiplied (one chunk is ~1150 matrix-core cycles
+    // per wave, an L2 round trip under load is longer: with a single stage every chunk waited for its loads)
+    struct Stage { RRStage<RR_MLP_BM> gx; RRStage<RR_MLP_VH> gv; RRStage<RR_MLP_PH> gp; };
+    Stage S0, S1;
     const int nchunk = (K + RR_MLP_KC - 1) / RR_MLP_KC;
     long long xoff[RRStage<RR_MLP_BM>::PER];       // start of this thread's observation rows (minibatch addressed in place)
 #pragma unroll
@@ -166,30 +189,35 @@ __global__ __launch_bounds__(256, 2) void rr_mlp_forward_kernel(const RRMlpArgs 
       const int n = (threadIdx.x + 256 * i) / RR_MLP_KC;
       xoff[i] = (n < RR_MLP_BM && row0 + n < M) ? (long long)(A.rows ? A.rows[row0 + n] : row0 + n) * K : -1;
     }
-    auto fetch = [&](int c) {
+    auto fetch = [&](Stage& S, int c) {
       const int k0 = c * RR_MLP_KC;
-      gx.fetch_at(A.obs, xoff, k0, K);
+      S.gx.fetch_at(A.obs, xoff, k0, K);
       if (A.mean) {      // normalise in registers: (x - mean) / std  (running_statistics.normalize)
 #pragma unroll
         for (int i = 0; i < RRStage<RR_MLP_BM>::PER; ++i) {
           const int kk = (threadIdx.x + 256 * i) % RR_MLP_KC;
-          if (k0 + kk < K) gx.r[i] = (gx.r[i] - A.mean[k0 + kk]) / A.std_[k0 + kk];
+          if (k0 + kk < K) S.gx.r[i] = (S.gx.r[i] - A.mean[k0 + kk]) / A.std_[k0 + kk];
         }
       }
-      if (has_val) gv.fetch(A.val.W[0], K, 0, RR_MLP_VH, k0, K);
-      if (has_pol) gp.fetch(A.pol.W[0], K, 0, RR_MLP_PH, k0, K);
+      if (has_val) S.gv.fetch(A.val.W[0], K, 0, RR_MLP_VH, k0, K);
+      if (has_pol) S.gp.fetch(A.pol.W[0], K, 0, RR_MLP_PH, k0, K);
     };
-    fetch(0);
-    for (int c = 0; c < nchunk; ++c) {
-      gx.commit(sX);
-      if (has_val) gv.commit(sW);
-      if (has_pol) gp.commit(sW + RR_MLP_VH * RR_SX);
+    auto step = [&](Stage& S, int c) {
+      S.gx.commit(sX);
+      if (has_val) S.gv.commit(sW);
+      if (has_pol) S.gp.commit(sW + RR_MLP_VH * RR_SX);
       __syncthreads();
-      if (c + 1 < nchunk) fetch(c + 1);
+      if (c + 2 < nchunk) fetch(S, c + 2);
       if (has_val && has_pol) rr_mlp_chunk<true, true>(sX, RR_SX, 0, sW, RR_MLP_VH, a0, a1, ap, lane, wv);
       else if (has_val) rr_mlp_chunk<true, false>(sX, RR_SX, 0, sW, RR_MLP_VH, a0, a1, ap, lane, wv);
       else rr_mlp_chunk<false, true>(sX, RR_SX, 0, sW, RR_MLP_VH, a0, a1, ap, lane, wv);
       __syncthreads();
+    };
+    fetch(S0, 0);
+    if (nchunk > 1) fetch(S1, 1);
+    for (int c = 0; c < nchunk; c += 2) {
+      step(S0, c);
+      if (c + 1 < nchunk) step(S1, c + 1);
     }
     if (has_val) rr_mlp_store_val(actV, a0, a1, A.val.b[0], lane, wv, A.val_act, row0, M);
     if (has_pol) rr_mlp_store_pol(actP, ap, A.pol.b[0], lane, wv, A.pol_act, row0, M);
@@ -200,16 +228,7 @@ __global__ __launch_bounds__(256, 2) void rr_mlp_forward_kernel(const RRMlpArgs 
   for (int l = 1; has_val && l < A.val.nlayers - 1; ++l) {
     rr_f16 a0 = {0}, a1 = {0};
     rr_f4 ap = {0, 0, 0, 0};
-    RRStage<RR_MLP_VH> gv;
-    constexpr int nchunk = RR_MLP_VH / RR_MLP_KC;
-    gv.fetch(A.val.W[l], RR_MLP_VH, 0, RR_MLP_VH, 0, RR_MLP_VH);
-    for (int c = 0; c < nchunk; ++c) {
-      gv.commit(sW);
-      __syncthreads();
-      if (c + 1 < nchunk) gv.fetch(A.val.W[l], RR_MLP_VH, 0, RR_MLP_VH, (c + 1) * RR_MLP_KC, RR_MLP_VH);
-      rr_mlp_chunk<true, false>(actV, RR_SV, c * RR_MLP_KC, sW, 0, a0, a1, ap, lane, wv);
-      __syncthreads();
-    }
+    rr_mlp_hidden_layer(A.val.W[l], actV, sW, a0, a1, ap, lane, wv);
     // every wave has read the whole input before anyone overwrites it (the barrier closing the last chunk)
     rr_mlp_store_val(actV, a0, a1, A.val.b[l], lane, wv, A.val_act ? A.val_act + (size_t)l * M * RR_MLP_VH : nullptr, row0, M);
     __syncthreads();
@@ -341,16 +360,7 @@ __global__ __launch_bounds__(256, 2) void rr_mlp_value_backward_kernel(const RRM
   for (int j = A.nh - 1; j >= 1; --j) {
     rr_f16 a0 = {0}, a1 = {0};
     rr_f4 ap = {0, 0, 0, 0};
-    RRStage<RR_MLP_VH> gv;
-    constexpr int nchunk = RR_MLP_VH / RR_MLP_KC;
-    gv.fetch(A.Wt[j], RR_MLP_VH, 0, RR_MLP_VH, 0, RR_MLP_VH);
-    for (int c = 0; c < nchunk; ++c) {
-      gv.commit(sW);
-      __syncthreads();
-      if (c + 1 < nchunk) gv.fetch(A.Wt[j], RR_MLP_VH, 0, RR_MLP_VH, (c + 1) * RR_MLP_KC, RR_MLP_VH);
-      rr_mlp_chunk<true, false>(actV, RR_SV, c * RR_MLP_KC, sW, 0, a0, a1, ap, lane, wv);
-      __syncthreads();
-    }
+    rr_mlp_hidden_layer(A.Wt[j], actV, sW, a0, a1, ap, lane, wv);
     rr_mlp_bwd_epilogue<false>(A, j - 1, actV, a0, a1, nullptr, lane, wv, row0);
     __syncthreads();
   }

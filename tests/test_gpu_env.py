@@ -164,3 +164,65 @@ def test_simd_pairing_schedule_is_result_neutral():
     act = torch.rand(N, a.action_size, device="cuda:0", generator=g) * 2 - 1
     sa2, sb2 = a.step(sa, act), b.step(sb, act)
     assert torch.equal(sa2.obs, sb2.obs) and torch.equal(sa2.pipeline_state.qvel, sb2.pipeline_state.qvel)
+
+
+def test_graph_replay_and_sub_batches_equal_host_issued_steps():
+    """(1) Replaying a HIP graph of R wrapped env steps (`envs.graphed.GraphedSteps`) leaves the same state, bit for bit, as issuing
+    the steps from the host.  (2) Stepping the batch as two sub-batches on two streams gives every env the same trajectory as the
+    whole batch in one launch (envs are independent; the split is a scheduling choice)."""
+    from rodent_amd import envs, jax_random
+    from rodent_amd.envs import graphed, wrappers
+    dev = torch.device("cuda:0")
+    N, R = 64, 3
+    keys = jax_random.split(jax_random.PRNGKey(5), N)
+    acts = (torch.rand(2 * R, N, 30, device=dev, generator=torch.Generator(device=dev).manual_seed(3)) * 2 - 1)
+
+    def make(n, keys_, stream):
+        with torch.cuda.stream(stream):
+            env = envs.get_environment("rodent", track_pos=util.synthetic_track(), num_envs=n, xml_path="rodent_optimized.xml",
+                                       iterations=8, ls_iterations=8, device=dev)
+            wenv = wrappers.wrap(env, episode_length=4, action_repeat=1)           # short episodes: the auto-reset path is exercised
+            return wenv, wenv.reset(keys_)
+
+    def run_host(wenv, state, a, stream):
+        with torch.cuda.stream(stream):
+            for t in range(a.shape[0]):
+                state = wenv.step(state, a[t])
+        return state
+
+    s0 = torch.cuda.Stream(dev)
+    wenv, st = make(N, keys, s0)
+    want = run_host(wenv, st, acts, s0)
+    torch.cuda.synchronize()
+    # (1) graph replay; the action of a step is read through a cursor kept on the device (a replay cannot take host arguments)
+    wenv_g, st_g = make(N, keys, s0)
+    cursor = torch.zeros((), dtype=torch.long, device=dev)
+
+    def step_fn(state):
+        a = acts.index_select(0, cursor.reshape(1))[0]
+        cursor.add_(1)
+        return wenv_g.step(state, a)
+    with torch.cuda.stream(s0):
+        st1 = step_fn(st_g)                                   # host-issued first step: the template must be a step OUTPUT
+    torch.cuda.synchronize()
+    g = graphed.GraphedSteps(step_fn, st1, R, s0)             # capture only records: the cursor still reads 1
+    got = g.replay()                                          # steps 2 .. R+1
+    torch.cuda.synchronize()
+    assert int(cursor) == 1 + R
+    want_r = run_host(wenv_r := make(N, keys, s0)[0], wenv_r.reset(keys), acts[:1 + R], s0)
+    torch.cuda.synchronize()
+    la, lb = graphed.tree_leaves(got), graphed.tree_leaves(want_r)
+    assert len(la) == len(lb) > 10
+    for x, y in zip(la, lb):
+        assert x.shape == y.shape and torch.equal(x, y)
+    # (2) two sub-batches on two streams
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    h = N // 2
+    w1, t1 = make(h, keys[:h], s1)
+    w2, t2 = make(h, keys[h:], s2)
+    o1, o2 = run_host(w1, t1, acts[:, :h], s1), run_host(w2, t2, acts[:, h:], s2)
+    torch.cuda.synchronize()
+    for name in ("obs", "reward", "done"):
+        assert torch.equal(torch.cat([getattr(o1, name), getattr(o2, name)]), getattr(want, name)), name
+    assert torch.equal(torch.cat([o1.pipeline_state.qpos, o2.pipeline_state.qpos]), want.pipeline_state.qpos)
+    assert torch.equal(torch.cat([o1.info["steps"], o2.info["steps"]]), want.info["steps"])
