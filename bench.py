@@ -205,6 +205,15 @@ def main():
                     "CG 8/8, n_frames 10; step = one training step")
         batch = env._batch
         repeats_ms = [elapsed / len(timed) * 1e3]
+        extra["step_kernel_time_source"] = "hip events around the rollout's launches"
+        if batch.kernel_time()[1] == 0:
+            # the rollouts ran as sub-batches replayed from HIP graphs (acting.SubBatchRollout): events cannot be read back from a replayed
+            # graph, so the step kernel is timed on a short host-issued pass of the same env batch (random actions)
+            st_ = env.reset(0)
+            for _ in range(30):
+                st_ = env.step(st_, torch.empty(N, env.action_size, device=dev).uniform_(-1.0, 1.0, generator=gen))
+            torch.cuda.synchronize(dev)
+            extra["step_kernel_time_source"] = "host-issued pass of 30 steps after training (rollouts are HIP-graph replays of sub-batches)"
     else:
         if args.config == 2:
             # The N envs of this GPU are stepped as S sub-batches of N / S envs, each with its own batch, stream, wrapper state and

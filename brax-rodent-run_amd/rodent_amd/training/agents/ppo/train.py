@@ -106,7 +106,20 @@ def train(
     perm_gen = torch.Generator(device="cpu")
     perm_gen.manual_seed(int(local_key[1]))
 
-    env_state = wenv.reset(key_envs)
+    # Optional (RR_ROLLOUT_SUBSTREAMS=2): the rollouts as S sub-batches on S streams, each unroll replayed from a HIP graph
+    # (acting.SubBatchRollout).  Off by default: it pays for the bare env step (bench config 2: 1.49 -> 1.43 ms) but not here --
+    # measured 1.22 s against 1.05 s of rollout per training step, because the 256-VGPR policy forward of one sub-batch cannot
+    # be placed while the other sub-batch's step kernel fills the register files, so the two streams end up taking turns.
+    n_sub_streams = int(os.environ.get("RR_ROLLOUT_SUBSTREAMS", "1"))
+    sub_rollout = None
+    if (device.type == "cuda" and n_sub_streams > 1 and hasattr(env, "with_num_envs") and local_num_envs % n_sub_streams == 0
+            and local_num_envs // n_sub_streams >= int(os.environ.get("RR_ROLLOUT_SUBSTREAMS_MIN_ENVS", "512"))):
+        sub_rollout = acting.SubBatchRollout(env, n_sub_streams, device, episode_length, action_repeat, unroll_length,
+                                             seed=int(local_key[1]) % (2 ** 31), use_graph=os.environ.get("RR_ROLLOUT_GRAPH", "1") == "1")
+        sub_rollout.reset(key_envs)
+        env_state = None
+    else:
+        env_state = wenv.reset(key_envs)
 
     ppo_network = network_factory(env.observation_size, env.action_size, device=device)
     dist = ppo_network.parametric_action_distribution
@@ -156,6 +169,7 @@ def train(
         if device.type == "cuda":
             torch.cuda.synchronize(device)
 
+    rollout_policy = {"fn": None, "norm": None}
     gstate = {"graph": None, "graph_b": None, "calls": 0, "idx": None, "norm": None, "metrics": None, "failed": False}
 
     def adv_stats(adv):
@@ -251,9 +265,20 @@ def train(
     def training_step():
         nonlocal env_state, normalizer_params
         t0 = time.time()
-        policy = make_policy(current_params())
-        for u in range(U):
-            env_state = acting.generate_unroll(wenv, env_state, policy, buf, u, gen)
+        if sub_rollout is not None:
+            if rollout_policy["fn"] is None:             # ONE policy object for all training steps: the captured graphs hold it;
+                rollout_policy["norm"] = normalizer_params.clone() if normalize_observations else None     # it reads these buffers
+                rollout_policy["fn"] = make_policy((rollout_policy["norm"], policy_net))
+            elif normalize_observations:
+                for f in ("count", "mean", "summed_variance", "std"):
+                    getattr(rollout_policy["norm"], f).copy_(getattr(normalizer_params, f))
+            for u in range(U):
+                sub_rollout.unroll(rollout_policy["fn"], buf, u)
+            sub_rollout.join()
+        else:
+            policy = make_policy(current_params())
+            for u in range(U):
+                env_state = acting.generate_unroll(wenv, env_state, policy, buf, u, gen)
         sync()
         t1 = time.time()
         data = buf.flat()
@@ -303,7 +328,10 @@ def train(
             current_step = steps_done * env_step_per_training_step
             if num_resets_per_eval > 0 and not stop:
                 local_key, key_env = jax_random.split(local_key)
-                env_state = wenv.reset(jax_random.split(key_env, local_num_envs))
+                if sub_rollout is not None:
+                    sub_rollout.reset(jax_random.split(key_env, local_num_envs))
+                else:
+                    env_state = wenv.reset(jax_random.split(key_env, local_num_envs))
             if stop:
                 break
         if process_id == 0:

@@ -130,3 +130,28 @@ def test_two_ranks_share_the_gpu_through_the_hip_env(graph):
     np.testing.assert_array_equal(p0, p1)
     np.testing.assert_array_equal(m0, m1)
     assert c0 == c1 == 128 * 4 * 4 * 3
+
+
+def test_sub_batch_rollouts_replayed_equal_host_issued(monkeypatch):
+    """ppo.train with the rollouts as two sub-batches on two streams (acting.SubBatchRollout): replaying each unroll from a HIP
+    graph gives the parameters of the host-issued run, bit for bit."""
+    from rodent_amd import envs
+    from rodent_amd.training.agents.ppo import train as ppo
+    monkeypatch.setenv("RR_ROLLOUT_SUBSTREAMS", "2")
+    monkeypatch.setenv("RR_ROLLOUT_SUBSTREAMS_MIN_ENVS", "32")
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RR_ROLLOUT_GRAPH", mode)
+        env = envs.get_environment("rodent", track_pos=util.synthetic_track(), num_envs=128, xml_path="rodent_optimized.xml",
+                                   iterations=8, ls_iterations=8, device="cuda:0")
+        log = []
+        _, params, _ = ppo.train(environment=env, num_timesteps=128 * 4 * 4 * 3, episode_length=150, num_envs=128, batch_size=128,
+                                 num_minibatches=4, unroll_length=4, num_updates_per_batch=2, num_evals=1, num_eval_envs=0,
+                                 learning_rate=5e-5, entropy_cost=1e-3, discounting=0.97, normalize_observations=True, seed=3,
+                                 progress_fn=lambda n, m: log.append(m))
+        assert math.isfinite(float(log[-1]["training/total_loss"]))
+        out[mode] = ([p.detach().clone() for p in params[1].parameters()], params[0].mean.clone(), float(params[0].count))
+    assert out["1"][2] == out["0"][2] == 128 * 4 * 4 * 3
+    assert torch.equal(out["1"][1], out["0"][1])                                     # same observations seen
+    for a, b in zip(out["1"][0], out["0"][0]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
