@@ -71,7 +71,8 @@ class GraphedSteps:
         self.graph = torch.cuda.CUDAGraph()
         for g in generators:
             self.graph.register_generator_state(g)
-        with torch.cuda.graph(self.graph, stream=stream):
+        # thread_local: a process group's watchdog thread may query events while this thread captures (multi-GPU runs)
+        with torch.cuda.graph(self.graph, stream=stream, capture_error_mode="thread_local"):
             s = self.state
             for _ in range(steps_per_replay):
                 s = step_fn(s)

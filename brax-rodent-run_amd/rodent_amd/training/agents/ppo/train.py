@@ -240,13 +240,13 @@ def train(
                 torch.cuda.synchronize(device)
                 npar = gstate["norm"] if normalize_observations else normalizer_params
                 if process_count == 1:
-                    with torch.cuda.graph(g):
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         gstate["metrics"] = eager_update(data, gstate["idx"], npar)
                 else:                            # capture records, it does not run: both halves are replayed below
-                    with torch.cuda.graph(g):
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         gstate["metrics"] = fwd_bwd(data, gstate["idx"], npar)
                     gb = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gb):
+                    with torch.cuda.graph(gb, capture_error_mode="thread_local"):
                         optimizer.step()
                     gstate["graph_b"] = gb
                 gstate["graph"] = g

@@ -226,3 +226,47 @@ def test_graph_replay_and_sub_batches_equal_host_issued_steps():
         assert torch.equal(torch.cat([getattr(o1, name), getattr(o2, name)]), getattr(want, name)), name
     assert torch.equal(torch.cat([o1.pipeline_state.qpos, o2.pipeline_state.qpos]), want.pipeline_state.qpos)
     assert torch.equal(torch.cat([o1.info["steps"], o2.info["steps"]]), want.info["steps"])
+
+
+def _nccl_graph_worker(port, out):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from rodent_amd import envs, jax_random
+        from rodent_amd.envs import graphed, wrappers
+        dev = torch.device("cuda:0")
+        t = torch.ones(4, device=dev)
+        torch.distributed.all_reduce(t)                       # the communicator and its watchdog thread are live
+        st = torch.cuda.Stream(dev)
+        with torch.cuda.stream(st):
+            env = envs.get_environment("rodent", track_pos=util.synthetic_track(), num_envs=32, xml_path="rodent_optimized.xml",
+                                       iterations=8, ls_iterations=8, device=dev)
+            wenv = wrappers.wrap(env, episode_length=150, action_repeat=1)
+            gen = torch.Generator(device=dev); gen.manual_seed(1)
+            state = wenv.reset(jax_random.split(jax_random.PRNGKey(0), 32))
+
+            def step_fn(s):
+                return wenv.step(s, torch.empty(32, env.action_size, device=dev).uniform_(-1.0, 1.0, generator=gen))
+            state = step_fn(state)
+        torch.cuda.synchronize()
+        g = graphed.GraphedSteps(step_fn, state, 5, st, [gen])
+        for _ in range(4):
+            s = g.replay()
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+        out["ok"] = bool(torch.isfinite(s.obs).all()) and float(s.info["steps"].max()) > 0
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+def test_graph_capture_next_to_an_rccl_communicator():
+    """bench.py's multi-GPU run captures the step while an RCCL process group (and its watchdog thread) is alive."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        p = ctx.Process(target=_nccl_graph_worker, args=(29731, out))
+        p.start(); p.join(180)
+        assert p.exitcode == 0 and out.get("ok") is True
