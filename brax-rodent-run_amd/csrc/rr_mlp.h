@@ -19,6 +19,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #define RR_MLP_BM 32        // observation rows per workgroup
 #define RR_MLP_KC 16        // k-chunk staged through LDS
@@ -56,32 +57,50 @@ constexpr int RR_MLP_LDS_FLOATS = RR_MLP_BM * RR_SX + RR_WROWS * RR_SX + RR_MLP_
 
 // Stage rows [row0, row0+nrows) x k [k0, k0+KC) of a row-major matrix (leading dimension ld, valid k < K, valid rows < R) in
 // two steps: `fetch` issues the global loads into registers, `commit` writes them to LDS (so loads fly during the MFMAs).
+// The tile moves in 16-byte pieces (global_load_dwordx4; rows may start at any 4-byte boundary, K = 1263): element-wise staging
+// cost as many issue cycles per chunk as the chunk's matrix-core work.  The LDS rows are 72 bytes apart: two 8-byte stores.
+typedef float rr_f2v __attribute__((ext_vector_type(2)));
+typedef float rr_f4u __attribute__((ext_vector_type(4), aligned(4)));
 template <int NROWS>
 struct RRStage {
-  static constexpr int PER = (NROWS * RR_MLP_KC + 255) / 256;
-  float r[PER];
+  static constexpr int NV = NROWS * RR_MLP_KC / 4;      // float4 pieces of the tile; piece v = row v / 4, floats 4 (v % 4) ..
+  static constexpr int PER = (NV + 255) / 256;
+  rr_f4 r[PER];
+  // No branches around the loads (a conditional load cannot be speculated: the compiler turns it into divergent control flow
+  // with a full s_waitcnt inside, which serialises the prefetch): rows are CLAMPED into the matrix -- the outputs of the
+  // duplicated rows are never stored -- and only the last, partial k-chunk (FULL = false) masks, element-wise, by select.
+  template <bool FULL>
+  static __device__ __forceinline__ rr_f4 load4(const float* row, int k, int K) {
+    if (FULL) { const rr_f4u u = *(const rr_f4u*)(row + k); return rr_f4{u[0], u[1], u[2], u[3]}; }
+    rr_f4 t;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float x = row[min(k + j, K - 1)]; t[j] = k + j < K ? x : 0.0f; }
+    return t;
+  }
+  template <bool FULL>
   __device__ __forceinline__ void fetch(const float* src, int ld, int row0, int R, int k0, int K) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const int e = threadIdx.x + 256 * i, n = e / RR_MLP_KC, kk = e % RR_MLP_KC;
-      const bool ok = e < NROWS * RR_MLP_KC && row0 + n < R && k0 + kk < K;
-      r[i] = ok ? src[(size_t)(row0 + n) * ld + k0 + kk] : 0.0f;
+      const int v = min((int)threadIdx.x + 256 * i, NV - 1), n = min(row0 + (v >> 2), R - 1);
+      r[i] = load4<FULL>(src + (size_t)n * ld, k0 + 4 * (v & 3), K);
     }
   }
-  // same, element i of this thread reading from the row that starts at src + off[i] (off < 0: no such row); the offsets are
-  // the same for every chunk (a thread keeps its tile rows), so the caller looks the row indices up once
+  // same, piece i of this thread reading from the row that starts at src + off[i]; the offsets are the same for every chunk
+  // (a thread keeps its tile rows), so the caller looks the row indices up once
+  template <bool FULL>
   __device__ __forceinline__ void fetch_at(const float* src, const long long (&off)[PER], int k0, int K) {
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int kk = (threadIdx.x + 256 * i) % RR_MLP_KC;
-      r[i] = (off[i] >= 0 && k0 + kk < K) ? src[off[i] + k0 + kk] : 0.0f;
-    }
+    for (int i = 0; i < PER; ++i) r[i] = load4<FULL>(src + off[i], k0 + 4 * ((threadIdx.x + 256 * i) & 3), K);
   }
   __device__ __forceinline__ void commit(float* dst /* [NROWS][RR_SX] */) const {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const int e = threadIdx.x + 256 * i, n = e / RR_MLP_KC, kk = e % RR_MLP_KC;
-      if (e < NROWS * RR_MLP_KC) dst[n * RR_SX + kk] = r[i];
+      const int v = threadIdx.x + 256 * i;
+      if (v < NV) {
+        float* d = dst + (v >> 2) * RR_SX + 4 * (v & 3);
+        *(rr_f2v*)d = rr_f2v{r[i][0], r[i][1]};
+        *(rr_f2v*)(d + 2) = rr_f2v{r[i][2], r[i][3]};
+      }
     }
   }
 };
@@ -115,18 +134,18 @@ __device__ __forceinline__ void rr_mlp_chunk(const float* xa, int sa, int ka, co
 __device__ __forceinline__ void rr_mlp_hidden_layer(const float* W, const float* actV, float* sW, rr_f16& a0, rr_f16& a1, rr_f4& ap, int lane, int wv) {
   constexpr int nchunk = RR_MLP_VH / RR_MLP_KC;
   RRStage<RR_MLP_VH> g0, g1;
-  g0.fetch(W, RR_MLP_VH, 0, RR_MLP_VH, 0, RR_MLP_VH);
-  g1.fetch(W, RR_MLP_VH, 0, RR_MLP_VH, RR_MLP_KC, RR_MLP_VH);
+  g0.fetch<true>(W, RR_MLP_VH, 0, RR_MLP_VH, 0, RR_MLP_VH);
+  g1.fetch<true>(W, RR_MLP_VH, 0, RR_MLP_VH, RR_MLP_KC, RR_MLP_VH);
 #pragma unroll 1
   for (int c = 0; c < nchunk; c += 2) {
     g0.commit(sW);
     __syncthreads();
-    if (c + 2 < nchunk) g0.fetch(W, RR_MLP_VH, 0, RR_MLP_VH, (c + 2) * RR_MLP_KC, RR_MLP_VH);
+    if (c + 2 < nchunk) g0.fetch<true>(W, RR_MLP_VH, 0, RR_MLP_VH, (c + 2) * RR_MLP_KC, RR_MLP_VH);
     rr_mlp_chunk<true, false>(actV, RR_SV, c * RR_MLP_KC, sW, 0, a0, a1, ap, lane, wv);
     __syncthreads();
     g1.commit(sW);
     __syncthreads();
-    if (c + 3 < nchunk) g1.fetch(W, RR_MLP_VH, 0, RR_MLP_VH, (c + 3) * RR_MLP_KC, RR_MLP_VH);
+    if (c + 3 < nchunk) g1.fetch<true>(W, RR_MLP_VH, 0, RR_MLP_VH, (c + 3) * RR_MLP_KC, RR_MLP_VH);
     rr_mlp_chunk<true, false>(actV, RR_SV, (c + 1) * RR_MLP_KC, sW, 0, a0, a1, ap, lane, wv);
     __syncthreads();
   }
@@ -180,29 +199,45 @@ __global__ __launch_bounds__(256, 2) void rr_mlp_forward_kernel(const RRMlpArgs 
     rr_f4 ap = {0, 0, 0, 0};
     // TWO register stages: the loads of chunk c+2 are issued while chunk c is multiplied (one chunk is ~1150 matrix-core cycles
     // per wave, an L2 round trip under load is longer: with a single stage every chunk waited for its loads)
-    struct Stage { RRStage<RR_MLP_BM> gx; RRStage<RR_MLP_VH> gv; RRStage<RR_MLP_PH> gp; };
+    struct Stage { RRStage<RR_MLP_BM> gx; RRStage<RR_MLP_VH> gv; RRStage<RR_MLP_PH> gp; rr_f4 mu[RRStage<RR_MLP_BM>::PER], sd[RRStage<RR_MLP_BM>::PER]; };
     Stage S0, S1;
     const int nchunk = (K + RR_MLP_KC - 1) / RR_MLP_KC;
     long long xoff[RRStage<RR_MLP_BM>::PER];       // start of this thread's observation rows (minibatch addressed in place)
 #pragma unroll
     for (int i = 0; i < RRStage<RR_MLP_BM>::PER; ++i) {
-      const int n = (threadIdx.x + 256 * i) / RR_MLP_KC;
-      xoff[i] = (n < RR_MLP_BM && row0 + n < M) ? (long long)(A.rows ? A.rows[row0 + n] : row0 + n) * K : -1;
+      const int v = min((int)threadIdx.x + 256 * i, RRStage<RR_MLP_BM>::NV - 1), m = min(row0 + (v >> 2), M - 1);   // clamped: see RRStage
+      xoff[i] = (long long)(A.rows ? A.rows[m] : m) * K;
     }
-    auto fetch = [&](Stage& S, int c) {
+    auto fetch_t = [&](Stage& S, int c, auto full) {
+      constexpr bool FULL = decltype(full)::value;
       const int k0 = c * RR_MLP_KC;
-      S.gx.fetch_at(A.obs, xoff, k0, K);
-      if (A.mean) {      // normalise in registers: (x - mean) / std  (running_statistics.normalize)
-#pragma unroll
+      S.gx.template fetch_at<FULL>(A.obs, xoff, k0, K);
+      if (A.mean) {      // the normaliser's chunk rides along; it is APPLIED at commit time (arithmetic on the loaded values here
+#pragma unroll       // would wait for them -- and for every older load -- inside the fetch, i.e. no load would ever fly during the MFMAs)
         for (int i = 0; i < RRStage<RR_MLP_BM>::PER; ++i) {
-          const int kk = (threadIdx.x + 256 * i) % RR_MLP_KC;
-          if (k0 + kk < K) S.gx.r[i] = (S.gx.r[i] - A.mean[k0 + kk]) / A.std_[k0 + kk];
+          const int k = k0 + 4 * ((threadIdx.x + 256 * i) & 3);
+          S.mu[i] = RRStage<RR_MLP_BM>::template load4<FULL>(A.mean, k, K);
+          S.sd[i] = RRStage<RR_MLP_BM>::template load4<FULL>(A.std_, k, K);
+          if (!FULL) {     // columns past K: x = mean = 0 there, keep the quotient finite (it meets zero weights)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) S.sd[i][j] = k + j < K ? S.sd[i][j] : 1.0f;
+          }
         }
       }
-      if (has_val) S.gv.fetch(A.val.W[0], K, 0, RR_MLP_VH, k0, K);
-      if (has_pol) S.gp.fetch(A.pol.W[0], K, 0, RR_MLP_PH, k0, K);
+      if (has_val) S.gv.template fetch<FULL>(A.val.W[0], K, 0, RR_MLP_VH, k0, K);
+      if (has_pol) S.gp.template fetch<FULL>(A.pol.W[0], K, 0, RR_MLP_PH, k0, K);
+    };
+    auto fetch = [&](Stage& S, int c) {            // uniform branch: only the last chunk can be partial
+      if ((c + 1) * RR_MLP_KC <= K) fetch_t(S, c, std::true_type{});
+      else fetch_t(S, c, std::false_type{});
     };
     auto step = [&](Stage& S, int c) {
+      if (A.mean) {      // normalise in registers: (x - mean) / std  (running_statistics.normalize); columns past K meet zero weights
+#pragma unroll
+        for (int i = 0; i < RRStage<RR_MLP_BM>::PER; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) S.gx.r[i][j] = (S.gx.r[i][j] - S.mu[i][j]) / S.sd[i][j];
+      }
       S.gx.commit(sX);
       if (has_val) S.gv.commit(sW);
       if (has_pol) S.gp.commit(sW + RR_MLP_VH * RR_SX);
@@ -340,7 +375,12 @@ __device__ __forceinline__ void rr_mlp_bwd_epilogue(const RRMlpBwdArgs& A, int j
   }
 }
 
-__global__ __launch_bounds__(256, 2) void rr_mlp_value_backward_kernel(const RRMlpBwdArgs A) {
+// three workgroups per CU (51.5 KB of LDS each, <= 168 VGPRs): the 704 workgroups of the launcher's minibatch are resident at once;
+// at two per CU (512 slots) they ran as two rounds, the second 37 % full: 0.277 -> 0.215 ms
+#ifndef RR_MLP_BWD_WGS
+#define RR_MLP_BWD_WGS 3
+#endif
+__global__ __launch_bounds__(256, RR_MLP_BWD_WGS) void rr_mlp_value_backward_kernel(const RRMlpBwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* sW = lds;                                   // [256][18]  chunk of W_j transposed
   float* actV = sW + RR_MLP_VH * RR_SX;              // [32][258]  delta tile
@@ -421,35 +461,72 @@ __global__ __launch_bounds__(256, 2) void rr_mlp_dw_kernel(const RRDwArgs A) {
   for (int x = 0; x < WO; ++x)
 #pragma unroll
     for (int y = 0; y < WI; ++y) acc[x][y] = rr_f16{0};
-  float ra[PA], rb[PB];
-  long long boff[PB];               // start of b's row of this thread's elements in the NEXT chunk to fetch (-1: past the slice)
+  // staging in 16-byte pieces: a thread moves PA/4 + PB/4 float4 per chunk (global_load_dwordx4 -> ds_write_b128); four times fewer
+  // memory instructions and address computations than element-wise staging, which cost as many issue cycles as the matrix-core
+  // work of a chunk.  Rows of b may start at any 4-byte boundary (I = 1263): the vector type carries 4-byte alignment.
+  // No branches around the loads (see RRStage): rows past the slice are CLAMPED to its last row and the a-piece is zeroed by
+  // select (0 * finite = 0); workgroups whose tile overhangs the matrix (last tile column / row, or O not a multiple of 4) take
+  // the element-wise path -- a workgroup-uniform choice.
+  constexpr int VA = PA / 4, VB = PB / 4;
+  static_assert(PA % 4 == 0 && PB % 4 == 0, "whole float4 per thread");
+  // Three workgroup-uniform cases.  `whole`: the tile lies inside the matrix and a's rows are 16-byte aligned: aligned vector loads,
+  // ds_write_b128.  Overhanging tile (last tile column / row): a piece that would cross the edge is loaded from the last four columns
+  // instead (start clamped to width - 4) and written to the LDS columns it really holds -- it overlaps its neighbour with identical
+  // values; LDS columns past the edge keep stale data and only feed outputs that are never stored.  Width < 4: element-wise.
+  const bool whole = (A.O & 3) == 0 && o0 + TO <= A.O && i0 + TI <= A.I;
+  const bool vec_a = A.O - o0 >= 4, vec_b = A.I - i0 >= 4;        // at least one whole piece inside the matrix
+  int acol[VA], bcol[VB];           // first tile column of this thread's pieces (loop invariant)
+#pragma unroll
+  for (int q = 0; q < VA; ++q) { const int c = 4 * ((threadIdx.x + 256 * q) % (TO / 4)); acol[q] = vec_a ? min(o0 + c, A.O - 4) - o0 : c; }
+#pragma unroll
+  for (int q = 0; q < VB; ++q) { const int c = 4 * ((threadIdx.x + 256 * q) % (TI / 4)); bcol[q] = vec_b ? min(i0 + c, A.I - 4) - i0 : c; }
+  rr_f4 ra[VA], rb[VB];
+  long long boff[VB];               // start of b's row of this thread's pieces in the NEXT chunk to fetch
   auto lookup = [&](int mc) {       // one chunk ahead of the loads that use it, so the index load is never on their critical path
 #pragma unroll
-    for (int q = 0; q < PB; ++q) {
-      const int m = mc + (threadIdx.x + 256 * q) / TI;
-      boff[q] = m < m1 ? (long long)(A.rows ? A.rows[m] : m) * A.I : -1;
+    for (int q = 0; q < VB; ++q) {
+      const int m = min(mc + (int)(threadIdx.x + 256 * q) / (TI / 4), m1 - 1);
+      boff[q] = (long long)(A.rows ? A.rows[m] : m) * A.I;
     }
   };
-  auto fetch = [&](int mc) {
+  auto load4 = [&](const float* p, bool vec, int col, int width) {     // p = row start + tile start
+    rr_f4 t;
+    if (vec) { const rr_f4u tu = *(const rr_f4u*)(p + col); t = rr_f4{tu[0], tu[1], tu[2], tu[3]}; }
+    else {
 #pragma unroll
-    for (int q = 0; q < PA; ++q) {
-      const int e = threadIdx.x + 256 * q, kk = e / TO, oo = e % TO, m = mc + kk;
-      ra[q] = (m < m1 && o0 + oo < A.O) ? A.a[(size_t)m * A.O + o0 + oo] : 0.0f;
+      for (int u = 0; u < 4; ++u) t[u] = p[min(col + u, width - 1)];
+    }
+    return t;
+  };
+  auto fetch = [&](int mc) {        // no arithmetic on the loaded values here: it would wait for the loads
+#pragma unroll
+    for (int q = 0; q < VA; ++q) {
+      const int m = min(mc + (int)(threadIdx.x + 256 * q) / (TO / 4), m1 - 1);
+      const float* p = A.a + (size_t)m * A.O + o0;
+      if (whole) ra[q] = *(const rr_f4*)(p + acol[q]);
+      else ra[q] = load4(p, vec_a, acol[q], A.O - o0);
     }
 #pragma unroll
-    for (int q = 0; q < PB; ++q) {
-      const int ii = (threadIdx.x + 256 * q) % TI;
-      rb[q] = (boff[q] >= 0 && i0 + ii < A.I) ? A.b[boff[q] + i0 + ii] : 0.0f;
-    }
+    for (int q = 0; q < VB; ++q) rb[q] = load4(A.b + boff[q] + i0, whole || vec_b, bcol[q], A.I - i0);
   };
   lookup(m0);
   fetch(m0);
   lookup(m0 + KC);
   for (int mc = m0; mc < m1; mc += KC) {
 #pragma unroll
-    for (int q = 0; q < PA; ++q) { const int e = threadIdx.x + 256 * q; sA[(e / TO) * SA + e % TO] = ra[q]; }
+    for (int q = 0; q < VA; ++q) {
+      const int kk = (threadIdx.x + 256 * q) / (TO / 4);
+      const rr_f4 t = mc + kk < m1 ? ra[q] : rr_f4{0.0f, 0.0f, 0.0f, 0.0f};       // rows past the slice contribute nothing
+      float* d = sA + kk * SA + acol[q];
+      if (whole) *(rr_f4*)d = t;
+      else { d[0] = t[0]; d[1] = t[1]; d[2] = t[2]; d[3] = t[3]; }
+    }
 #pragma unroll
-    for (int q = 0; q < PB; ++q) { const int e = threadIdx.x + 256 * q; sB[(e / TI) * SB + e % TI] = rb[q]; }
+    for (int q = 0; q < VB; ++q) {
+      float* d = sB + ((threadIdx.x + 256 * q) / (TI / 4)) * SB + bcol[q];
+      if (whole) *(rr_f4*)d = rb[q];
+      else { d[0] = rb[q][0]; d[1] = rb[q][1]; d[2] = rb[q][2]; d[3] = rb[q][3]; }
+    }
     __syncthreads();
     if (mc + KC < m1) { fetch(mc + KC); lookup(mc + 2 * KC); }
     const float* pa = sA + (lane >> 5) * SA + woff + (lane & 31);
