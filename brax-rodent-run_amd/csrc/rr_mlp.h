@@ -52,8 +52,17 @@ __device__ __forceinline__ float rr_silu(float v) { return v / (1.0f + expf(-v))
 constexpr int RR_SX = RR_MLP_KC + 2;        // stage stride (18): 18 n mod 64 is a bijection of n = 0..31 onto the even banks
 constexpr int RR_SV = RR_MLP_VH + 2;        // value activation stride (258)
 constexpr int RR_SP = RR_MLP_PH + 2;        // policy activation stride (34)
-constexpr int RR_WROWS = RR_MLP_VH + 64;    // staged weight rows: 256 value + up to 64 policy
-constexpr int RR_MLP_LDS_FLOATS = RR_MLP_BM * RR_SX + RR_WROWS * RR_SX + RR_MLP_BM * RR_SV + RR_MLP_BM * RR_SP;
+// LDS of the forward kernel, 51.5 KB so that THREE workgroups share a CU (the 704 workgroups of the launcher's minibatch are then one
+// resident round; at two per CU the second round was 37 % full).  Two regions, reused by phase:
+//   A [32][258]  layer 1: observation chunk [32][18] + weight chunk [288][18] (value rows 0..255, policy 256..287);
+//                afterwards the value activations (written by layer 1's epilogue, when every wave is done with the stage)
+//   B [256][18]  policy layers 2..head (run right after layer 1): their whole weight matrix [2 x 64][18] at the bottom, the policy
+//                activations [32][34] above it; then, the policy being finished, the weight chunks of the value hidden layers
+constexpr int RR_MLP_LDS_A = RR_MLP_BM * RR_SV, RR_MLP_LDS_B = RR_MLP_VH * RR_SX;
+constexpr int RR_MLP_ACTP_AT = 3072;        // actP inside B (above the 2304 floats of the policy weights)
+constexpr int RR_MLP_LDS_FLOATS = RR_MLP_LDS_A + RR_MLP_LDS_B;
+static_assert(RR_MLP_BM * RR_SX + (RR_MLP_VH + RR_MLP_PH) * RR_SX <= RR_MLP_LDS_A, "layer-1 stage fits region A");
+static_assert(2 * 64 * RR_SX <= RR_MLP_ACTP_AT && RR_MLP_ACTP_AT + RR_MLP_BM * RR_SP <= RR_MLP_LDS_B, "policy weights and activations fit region B");
 
 // Stage rows [row0, row0+nrows) x k [k0, k0+KC) of a row-major matrix (leading dimension ld, valid k < K, valid rows < R) in
 // two steps: `fetch` issues the global loads into registers, `commit` writes them to LDS (so loads fly during the MFMAs).
@@ -182,12 +191,19 @@ __device__ __forceinline__ void rr_mlp_store_pol(float* actP, const rr_f4& ap, c
   }
 }
 
-__global__ __launch_bounds__(256, 2) void rr_mlp_forward_kernel(const RRMlpArgs A) {
+#ifndef RR_MLP_FWD_WGS
+#define RR_MLP_FWD_WGS 3
+#endif
+#ifndef RR_MLP_STAGES
+#define RR_MLP_STAGES 1      // register stages of layer 1's chunks (2: chunk c+2 in flight during chunk c; needs more than 168 VGPRs)
+#endif
+__global__ __launch_bounds__(256, RR_MLP_FWD_WGS) void rr_mlp_forward_kernel(const RRMlpArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* sX = lds;                                   // [32][18]   normalised observation chunk
-  float* sW = sX + RR_MLP_BM * RR_SX;                // [320][18]  weight chunk: rows 0..255 value, 256.. policy
-  float* actV = sW + RR_WROWS * RR_SX;               // [32][258]
-  float* actP = actV + RR_MLP_BM * RR_SV;            // [32][34]
+  float* actV = lds;                                 // region A: [32][258] value activations ...
+  float* sX = lds;                                   //   ... during layer 1: [32][18] normalised observation chunk
+  float* sW = sX + RR_MLP_BM * RR_SX;                //   ... and [288][18] weight chunk: rows 0..255 value, 256..287 policy
+  float* sB = lds + RR_MLP_LDS_A;                    // region B: [256][18] weight chunks of the hidden layers / policy weights
+  float* actP = sB + RR_MLP_ACTP_AT;                 //   ... [32][34] policy activations
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int row0 = blockIdx.x * RR_MLP_BM;
   const bool has_val = A.val.nlayers > 0, has_pol = A.pol.nlayers > 0;
@@ -200,7 +216,11 @@ __global__ __launch_bounds__(256, 2) void rr_mlp_forward_kernel(const RRMlpArgs 
     // TWO register stages: the loads of chunk c+2 are issued while chunk c is multiplied (one chunk is ~1150 matrix-core cycles
     // per wave, an L2 round trip under load is longer: with a single stage every chunk waited for its loads)
     struct Stage { RRStage<RR_MLP_BM> gx; RRStage<RR_MLP_VH> gv; RRStage<RR_MLP_PH> gp; rr_f4 mu[RRStage<RR_MLP_BM>::PER], sd[RRStage<RR_MLP_BM>::PER]; };
+#if RR_MLP_STAGES == 2
     Stage S0, S1;
+#else
+    Stage S0;
+#endif
     const int nchunk = (K + RR_MLP_KC - 1) / RR_MLP_KC;
     long long xoff[RRStage<RR_MLP_BM>::PER];       // start of this thread's observation rows (minibatch addressed in place)
 #pragma unroll
@@ -242,45 +262,29 @@ __global__ __launch_bounds__(256, 2) void rr_mlp_forward_kernel(const RRMlpArgs 
       if (has_val) S.gv.commit(sW);
       if (has_pol) S.gp.commit(sW + RR_MLP_VH * RR_SX);
       __syncthreads();
-      if (c + 2 < nchunk) fetch(S, c + 2);
+      if (c + RR_MLP_STAGES < nchunk) fetch(S, c + RR_MLP_STAGES);
       if (has_val && has_pol) rr_mlp_chunk<true, true>(sX, RR_SX, 0, sW, RR_MLP_VH, a0, a1, ap, lane, wv);
       else if (has_val) rr_mlp_chunk<true, false>(sX, RR_SX, 0, sW, RR_MLP_VH, a0, a1, ap, lane, wv);
       else rr_mlp_chunk<false, true>(sX, RR_SX, 0, sW, RR_MLP_VH, a0, a1, ap, lane, wv);
       __syncthreads();
     };
+#if RR_MLP_STAGES == 2
     fetch(S0, 0);
     if (nchunk > 1) fetch(S1, 1);
     for (int c = 0; c < nchunk; c += 2) {
       step(S0, c);
       if (c + 1 < nchunk) step(S1, c + 1);
     }
+#else
+    fetch(S0, 0);
+    for (int c = 0; c < nchunk; ++c) step(S0, c);
+#endif
     if (has_val) rr_mlp_store_val(actV, a0, a1, A.val.b[0], lane, wv, A.val_act, row0, M);
     if (has_pol) rr_mlp_store_pol(actP, ap, A.pol.b[0], lane, wv, A.pol_act, row0, M);
     __syncthreads();
   }
 
-  // ------------------------------------------------------------------ value hidden layers 256 -> 256 (activations stay in LDS)
-  for (int l = 1; has_val && l < A.val.nlayers - 1; ++l) {
-    rr_f16 a0 = {0}, a1 = {0};
-    rr_f4 ap = {0, 0, 0, 0};
-    rr_mlp_hidden_layer(A.val.W[l], actV, sW, a0, a1, ap, lane, wv);
-    // every wave has read the whole input before anyone overwrites it (the barrier closing the last chunk)
-    rr_mlp_store_val(actV, a0, a1, A.val.b[l], lane, wv, A.val_act ? A.val_act + (size_t)l * M * RR_MLP_VH : nullptr, row0, M);
-    __syncthreads();
-  }
-  // value head 256 -> 1: eight lanes per row
-  if (has_val) {
-    const int l = A.val.nlayers - 1;
-    const int m = threadIdx.x >> 3, part = threadIdx.x & 7;
-    const float* w = A.val.W[l];
-    float s = 0.0f;
-#pragma unroll 8
-    for (int k = part; k < RR_MLP_VH; k += 8) s = fmaf(actV[m * RR_SV + k], w[k], s);
-    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
-    if (part == 0 && row0 + m < M) A.val_out[row0 + m] = s + A.val.b[l][0];
-  }
-
-  // ------------------------------------------------------------------ policy hidden layers 32 -> 32 and the head 32 -> out_dim
+  // ------------------------------------------------------------------ policy hidden layers 32 -> 32 and the head 32 -> out_dim (region B)
   for (int l = 1; has_pol && l < A.pol.nlayers; ++l) {
     const bool head = l == A.pol.nlayers - 1;
     const int nout = head ? A.pol.out_dim : RR_MLP_PH;
@@ -288,14 +292,14 @@ __global__ __launch_bounds__(256, 2) void rr_mlp_forward_kernel(const RRMlpArgs 
     // the whole weight matrix [nout <= 64][32] as two k-chunks side by side: chunk c of row n at sW[(64 c + n) * 18 ..]
     for (int e = threadIdx.x; e < 64 * RR_MLP_PH; e += 256) {
       const int n = e / RR_MLP_PH, k = e % RR_MLP_PH;
-      sW[(64 * (k / RR_MLP_KC) + n) * RR_SX + (k % RR_MLP_KC)] = n < nout ? A.pol.W[l][n * RR_MLP_PH + k] : 0.0f;
+      sB[(64 * (k / RR_MLP_KC) + n) * RR_SX + (k % RR_MLP_KC)] = n < nout ? A.pol.W[l][n * RR_MLP_PH + k] : 0.0f;
     }
     __syncthreads();
     if (!head) {
       rr_f16 d0 = {0}, d1 = {0};
       rr_f4 ap = {0, 0, 0, 0};
-      rr_mlp_chunk<false, true>(actP, RR_SP, 0, sW, 0, d0, d1, ap, lane, wv);
-      rr_mlp_chunk<false, true>(actP, RR_SP, RR_MLP_KC, sW, 64, d0, d1, ap, lane, wv);
+      rr_mlp_chunk<false, true>(actP, RR_SP, 0, sB, 0, d0, d1, ap, lane, wv);
+      rr_mlp_chunk<false, true>(actP, RR_SP, RR_MLP_KC, sB, 64, d0, d1, ap, lane, wv);
       __syncthreads();
       rr_mlp_store_pol(actP, ap, A.pol.b[l], lane, wv, A.pol_act ? A.pol_act + (size_t)l * M * RR_MLP_PH : nullptr, row0, M);
     } else {
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void rr_mlp_forward_kernel(const RRMlpArgs 
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           const float* xr = actP + (16 * mt + (lane & 15)) * RR_SP + c * RR_MLP_KC + (lane >> 4);
-          const float* w0 = sW + (64 * c + 16 * wv + (lane & 15)) * RR_SX + (lane >> 4);
+          const float* w0 = sB + (64 * c + 16 * wv + (lane & 15)) * RR_SX + (lane >> 4);
 #pragma unroll
           for (int kk = 0; kk < RR_MLP_KC; kk += 4) ap = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[kk], w0[kk], ap, 0, 0, 0);
         }
@@ -321,6 +325,27 @@ __global__ __launch_bounds__(256, 2) void rr_mlp_forward_kernel(const RRMlpArgs 
         }
       }
     }
+  }
+  __syncthreads();        // the policy is done with region B
+  // ------------------------------------------------------------------ value hidden layers 256 -> 256 (activations stay in LDS; weight chunks through region B)
+  for (int l = 1; has_val && l < A.val.nlayers - 1; ++l) {
+    rr_f16 a0 = {0}, a1 = {0};
+    rr_f4 ap = {0, 0, 0, 0};
+    rr_mlp_hidden_layer(A.val.W[l], actV, sB, a0, a1, ap, lane, wv);
+    // every wave has read the whole input before anyone overwrites it (the barrier closing the last chunk)
+    rr_mlp_store_val(actV, a0, a1, A.val.b[l], lane, wv, A.val_act ? A.val_act + (size_t)l * M * RR_MLP_VH : nullptr, row0, M);
+    __syncthreads();
+  }
+  // value head 256 -> 1: eight lanes per row
+  if (has_val) {
+    const int l = A.val.nlayers - 1;
+    const int m = threadIdx.x >> 3, part = threadIdx.x & 7;
+    const float* w = A.val.W[l];
+    float s = 0.0f;
+#pragma unroll 8
+    for (int k = part; k < RR_MLP_VH; k += 8) s = fmaf(actV[m * RR_SV + k], w[k], s);
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    if (part == 0 && row0 + m < M) A.val_out[row0 + m] = s + A.val.b[l][0];
   }
 }
 
