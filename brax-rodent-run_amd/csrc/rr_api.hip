@@ -462,6 +462,15 @@ extern "C" int rr_ppo_loss(const float* policy_logits, const float* values, cons
   return RR_OK;
 }
 
+extern "C" int rr_policy_sample(const float* logits, const float* noise, int32_t N, int32_t A, float min_std, float* action, float* raw_action,
+                                float* log_prob, void* stream) {
+  if (!logits || !noise || !action || !raw_action || !log_prob || N <= 0 || A <= 0) return fail(RR_EINVAL, "rr_policy_sample: bad argument");
+  hipLaunchKernelGGL(rr_policy_sample_kernel, dim3((N + 7) / 8), dim3(256), 0, (hipStream_t)stream, logits, noise, N, A, min_std, action,
+                     raw_action, log_prob);
+  HIPCHK(hipGetLastError());
+  return RR_OK;
+}
+
 // elementwise half of a hidden SiLU layer's backward (csrc/rr_ppo.h)
 static int silu_bwd_blocks(int M, int* rows_per_block) {
   const int target = 512;                                   // blocks: two per CU

@@ -219,3 +219,33 @@ __global__ __launch_bounds__(256) void rr_colsum_kernel(const float* __restrict_
     out[n] = u;
   }
 }
+
+// ------------------------------------------------------------------------------------------ the actor's head: sample, squash, log-prob
+// `NormalTanhDistribution` on the rollout path [UP brax.training.distribution; acting.actor_step]: from the policy logits
+// (loc | pre-softplus scale) and one standard-normal draw per action dimension,
+//   raw = loc + (softplus(s) + min_std) * eps,  action = tanh(raw),
+//   log_prob = sum_i [ -0.5 eps_i^2 - log scale_i - 0.5 log 2 pi - 2 (log 2 - raw_i - softplus(-2 raw_i)) ]
+// in ONE launch (32 lanes per env, one action dimension per lane) instead of the ~20 elementwise / reduction launches of the
+// composed tensor expression, which cost ~0.07 ms between two 1.5 ms env steps.  (z = (raw - loc) / scale is eps up to rounding;
+// the composed expression recomputes it, so the two log-probs differ by float32 rounding, as tested.)
+__global__ __launch_bounds__(256) void rr_policy_sample_kernel(const float* __restrict__ logits, const float* __restrict__ noise, int N, int A,
+                                                               float min_std, float* __restrict__ action, float* __restrict__ raw_out,
+                                                               float* __restrict__ logp) {
+  const int lane = threadIdx.x & 31;
+  const int n = blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (n >= N) return;
+  const float HALF_LOG_2PI = 0.91893853320467274178f, LOG2 = 0.69314718055994530942f;
+  const float* lg = logits + (size_t)n * 2 * A;
+  float lp = 0.0f;
+  for (int a = lane; a < A; a += 32) {
+    const float loc = lg[a], scale = rr_softplus(lg[A + a]) + min_std;
+    const float raw = loc + scale * noise[(size_t)n * A + a];
+    const float z = (raw - loc) / scale;
+    lp += -0.5f * z * z - logf(scale) - HALF_LOG_2PI - 2.0f * (LOG2 - raw - rr_softplus(-2.0f * raw));
+    raw_out[(size_t)n * A + a] = raw;
+    action[(size_t)n * A + a] = tanhf(raw);
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) lp += __shfl_xor(lp, o, 32);
+  if (lane == 0) logp[n] = lp;
+}

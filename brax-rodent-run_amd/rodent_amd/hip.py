@@ -49,7 +49,7 @@ class RRPpoCfg(C.Structure):
 
 EXPORTS = ["rr_model_load", "rr_model_dims", "rr_model_set_solver", "rr_model_set_solver_type", "rr_model_destroy", "rr_model_table", "rr_kernarg_layout", "rr_batch_create",
            "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset", "rr_pipeline_step_to", "rr_env_step_to",
-           "rr_compute_gae", "rr_mlp_forward", "rr_ppo_loss_workspace_bytes", "rr_ppo_loss", "rr_mlp_silu_backward_workspace_bytes", "rr_mlp_silu_backward", "rr_mlp_value_backward_workspace_bytes", "rr_mlp_value_backward", "rr_mlp_weight_grad_workspace_bytes", "rr_mlp_weight_grad", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_schedule", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
+           "rr_compute_gae", "rr_mlp_forward", "rr_ppo_loss_workspace_bytes", "rr_ppo_loss", "rr_policy_sample", "rr_mlp_silu_backward_workspace_bytes", "rr_mlp_silu_backward", "rr_mlp_value_backward_workspace_bytes", "rr_mlp_value_backward", "rr_mlp_weight_grad_workspace_bytes", "rr_mlp_weight_grad", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_schedule", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
 
 _lib = None
 
@@ -89,6 +89,7 @@ def lib():
         L.rr_ppo_loss_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
         L.rr_ppo_loss_workspace_bytes.restype = C.c_size_t
         L.rr_ppo_loss.argtypes = [C.c_void_p] * 9 + [C.c_int32] * 3 + [C.POINTER(RRPpoCfg)] + [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]
+        L.rr_policy_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rr_mlp_silu_backward_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
         L.rr_mlp_silu_backward_workspace_bytes.restype = C.c_size_t
         L.rr_mlp_silu_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -463,3 +464,15 @@ def mlp_weight_grad(delta, act, out, rows=None, mean=None, std=None, delta_colsu
                                     _ptr(mean, numel=I) if mean is not None else None, _ptr(std, numel=I) if std is not None else None,
                                     _ptr(delta_colsum, numel=O) if mean is not None else None, M, O, I, out.data_ptr(), ws.data_ptr(), ws.numel() * 4, C.c_void_p(torch.cuda.current_stream(delta.device).cuda_stream)))
     return out
+
+
+def policy_sample(logits, noise, min_std: float):
+    """(action, raw_action, log_prob) of the tanh-normal policy head in one launch (C ABI `rr_policy_sample`).
+    logits [N, 2A], noise [N, A]: contiguous float32 device tensors."""
+    N, P2 = logits.shape
+    A = P2 // 2
+    _ptr(logits); _ptr(noise, numel=N * A)
+    action, raw, lp = torch.empty(N, A, device=logits.device), torch.empty(N, A, device=logits.device), torch.empty(N, device=logits.device)
+    _check(lib().rr_policy_sample(logits.data_ptr(), noise.data_ptr(), N, A, min_std, action.data_ptr(), raw.data_ptr(), lp.data_ptr(),
+                                  C.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream)))
+    return action, raw, lp

@@ -178,6 +178,13 @@ int rr_ppo_loss(const float* policy_logits, const float* values, const float* ra
                 const rr_ppo_cfg* cfg, float* grad_logits, float* grad_values, float* metrics, void* workspace, size_t workspace_bytes,
                 void* stream);
 
+/* The actor's head on the rollout path, `NormalTanhDistribution` of brax.training.distribution as acting.actor_step uses it [UP;
+ * SURVEY.md a22]: logits [N][2A] = (loc | pre-softplus scale), noise [N][A] standard normal draws ->
+ * raw_action = loc + (softplus(scale) + min_std) * noise, action = tanh(raw_action), log_prob [N] of raw_action under the
+ * distribution (Normal log-density minus the tanh log-det-Jacobian, summed over the action dimensions).  One launch. */
+int rr_policy_sample(const float* logits, const float* noise, int32_t N, int32_t A, float min_std, float* action, float* raw_action,
+                     float* log_prob, void* stream);
+
 /* Elementwise half of the backward pass of one hidden SiLU layer of the networks above (the matrix products stay with the
  * caller): with g = delta_l W_l [M][H] and the layer's pre-activations z [M][H] (rr_mlp_forward's dumps),
  * delta = g * silu'(z), h = silu(z) (the operand of dW_l = delta_l' h) and bias_grad[n] = sum_m delta[m][n], in one pass

@@ -213,3 +213,25 @@ def test_forward_reads_the_minibatch_in_place():
     b = hip.mlp_forward(obs[rows].contiguous(), mean, std, pp, vp, want_pre=True)
     for x, y in zip(a, b):
         assert x.shape == y.shape and torch.equal(x, y)
+
+
+def test_policy_sample_kernel_matches_the_distribution():
+    from rodent_amd import hip
+    from rodent_amd.training.networks import NormalTanhDistribution
+    g = torch.Generator().manual_seed(4)
+    N, A = 2048, 30
+    logits, eps = torch.randn(N, 2 * A, generator=g) * 0.8, torch.randn(N, A, generator=g)
+    dist = NormalTanhDistribution(A)
+    loc, scale = dist._params(logits.double())
+    raw64 = loc + scale * eps.double()
+    act64, lp64 = torch.tanh(raw64), dist.log_prob(logits.double(), raw64)
+    loc32, scale32 = dist._params(logits)
+    raw32 = loc32 + scale32 * eps
+    lp32 = dist.log_prob(logits, raw32).double()
+    act, raw, lp = hip.policy_sample(logits.to(DEV), eps.to(DEV), dist.min_std)
+    torch.cuda.synchronize()
+    assert (raw.double().cpu() - raw64).abs().max() <= 2e-6 * raw64.abs().max()
+    assert (act.double().cpu() - act64).abs().max() <= 2e-6
+    err, err32 = (lp.double().cpu() - lp64).abs().max(), (lp32 - lp64).abs().max()
+    print(f"log_prob: kernel {err:.2e}  composed float32 {err32:.2e}  (|log_prob| up to {lp64.abs().max():.1f})")
+    assert err <= 3 * err32 + 1e-5
