@@ -471,6 +471,36 @@ extern "C" int rr_policy_sample(const float* logits, const float* noise, int32_t
   return RR_OK;
 }
 
+// policy network backward: the delta chain of the 32-wide stack in one launch (csrc/rr_ppo.h)
+static int pol_bwd_blocks(int M) { return std::max(1, std::min(1024, (M + 7) / 8)); }
+extern "C" size_t rr_policy_backward_workspace_bytes(int32_t M, int32_t nhidden) {
+  if (M <= 0 || nhidden <= 0) return 0;
+  return (size_t)nhidden * pol_bwd_blocks(M) * 32 * sizeof(float);
+}
+extern "C" int rr_policy_backward(const float* grad_logits, const float* head_weight, const float* const* hidden_weights, int32_t nhidden, int32_t M,
+                                  int32_t P, float* pre_act, int32_t pre_act_rows, float* delta, float* const* bias_grads, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  if (!grad_logits || !head_weight || !hidden_weights || !pre_act || !delta || !bias_grads || !workspace || M <= 0 || pre_act_rows < M)
+    return fail(RR_EINVAL, "rr_policy_backward: bad argument");
+  if (nhidden < 1 || nhidden > RR_POL_MAXL || P < 1 || P > 64) return fail(RR_EUNSUPPORTED, "rr_policy_backward: unsupported network shape");
+  if (workspace_bytes < rr_policy_backward_workspace_bytes(M, nhidden)) return fail(RR_EINVAL, "rr_policy_backward: workspace too small");
+  RRPolBwdArgs A;
+  memset(&A, 0, sizeof(A));
+  A.g = grad_logits; A.w_head = head_weight; A.z = pre_act; A.delta = delta; A.part = (float*)workspace; A.M = M; A.P = P; A.nh = nhidden; A.zrows = pre_act_rows;
+  A.nblk = pol_bwd_blocks(M);
+  for (int j = 0; j < nhidden; ++j) {
+    if (!bias_grads[j] || (j > 0 && !hidden_weights[j])) return fail(RR_EINVAL, "rr_policy_backward: null layer pointer");
+    A.bgrad[j] = bias_grads[j];
+    A.W[j] = j > 0 ? hidden_weights[j] : nullptr;
+  }
+  const size_t lds = ((size_t)P * 32 + (size_t)(nhidden - 1) * 1024) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(rr_policy_backward_kernel, dim3(A.nblk), dim3(256), lds, st, A);
+  hipLaunchKernelGGL(rr_policy_colsum_kernel, dim3(nhidden), dim3(256), 0, st, A);
+  HIPCHK(hipGetLastError());
+  return RR_OK;
+}
+
 // elementwise half of a hidden SiLU layer's backward (csrc/rr_ppo.h)
 static int silu_bwd_blocks(int M, int* rows_per_block) {
   const int target = 512;                                   // blocks: two per CU

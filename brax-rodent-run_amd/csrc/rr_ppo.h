@@ -249,3 +249,84 @@ __global__ __launch_bounds__(256) void rr_policy_sample_kernel(const float* __re
   for (int o = 16; o > 0; o >>= 1) lp += __shfl_xor(lp, o, 32);
   if (lane == 0) logp[n] = lp;
 }
+
+// ------------------------------------------------------------------------------------------ policy network, backward: the delta chain
+// The 32-wide policy stack is 0.1 GFLOP per minibatch -- nothing for the matrix cores, but as library calls its backward was four
+// small products, four elementwise passes and four column sums per update (~110 us of launches).  Here one launch: 32 lanes per
+// row (lane = hidden unit), all weights in LDS, the row's delta handed around the 32 lanes by shuffles:
+//   delta_{nh-1} = (g W_head) * silu'(z_{nh-1}),   delta_{j-1} = (delta_j W_j) * silu'(z_{j-1}),
+// writing delta_j (operand of dW_{j+1} = delta_{j+1}' h_j), h_j = silu(z_j) over the forward's dump, and per-block column sums of
+// delta_j (= db_j; fixed-order reduction by rr_policy_colsum_kernel).
+#define RR_POL_MAXL 8
+struct RRPolBwdArgs {
+  const float* g;                 // [M][P]  d loss / d logits
+  const float* w_head;            // [P][32]
+  const float* W[RR_POL_MAXL];    // W[j], j = 1 .. nh-1: [32 out][32 in] (torch layout)
+  float* z;                       // [nh][zrows][32]  pre-activations in, silu(z) out (rows 0 .. M-1 of each layer)
+  float* delta;                   // [nh][M][32]  out
+  float* part;                    // [nh][gridDim.x][32]
+  float* bgrad[RR_POL_MAXL];      // db_j [32]
+  int M, P, nh, nblk, zrows;      // zrows: rows per layer of z (>= M: the minibatch may carry bootstrap rows behind the M used ones)
+};
+__global__ __launch_bounds__(256) void rr_policy_backward_kernel(const RRPolBwdArgs A) {
+  extern __shared__ float sw[];                 // [P][32] head, then (nh - 1) x [32][32]
+  __shared__ float sh[RR_POL_MAXL][8][32];
+  const int lane = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  for (int e = threadIdx.x; e < A.P * 32; e += 256) sw[e] = A.w_head[e];
+  for (int j = 1; j < A.nh; ++j)
+    for (int e = threadIdx.x; e < 1024; e += 256) sw[A.P * 32 + (j - 1) * 1024 + e] = A.W[j][e];
+  __syncthreads();
+  float cs[RR_POL_MAXL];
+#pragma unroll
+  for (int j = 0; j < RR_POL_MAXL; ++j) cs[j] = 0.0f;
+  for (int row = blockIdx.x * 8 + rg; row < A.M; row += gridDim.x * 8) {
+    const float* gr = A.g + (size_t)row * A.P;
+    const float g0 = lane < A.P ? gr[lane] : 0.0f, g1 = lane + 32 < A.P ? gr[lane + 32] : 0.0f;
+    float acc = 0.0f;
+    for (int o = 0; o < A.P; ++o) acc = fmaf(o < 32 ? __shfl(g0, o, 32) : __shfl(g1, o - 32, 32), sw[o * 32 + lane], acc);
+#pragma unroll
+    for (int jj = 0; jj < RR_POL_MAXL; ++jj) {
+      const int j = A.nh - 1 - jj;             // nh-1 .. 0
+      if (j < 0) break;
+      const size_t i = ((size_t)j * A.M + row) * 32 + lane, iz = ((size_t)j * A.zrows + row) * 32 + lane;
+      const float zz = A.z[iz], s = 1.0f / (1.0f + expf(-zz));
+      const float d = acc * (s * (1.0f + zz * (1.0f - s)));
+      A.delta[i] = d;
+      A.z[iz] = zz * s;
+      cs[jj] += d;
+      if (j > 0) {
+        const float* w = sw + A.P * 32 + (j - 1) * 1024;
+        acc = 0.0f;
+#pragma unroll
+        for (int o = 0; o < 32; ++o) acc = fmaf(__shfl(d, o, 32), w[o * 32 + lane], acc);
+      }
+    }
+  }
+#pragma unroll
+  for (int jj = 0; jj < RR_POL_MAXL; ++jj) sh[jj][rg][lane] = cs[jj];
+  __syncthreads();
+  if (rg == 0) {
+    for (int jj = 0; jj < A.nh; ++jj) {
+      float t = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) t += sh[jj][r][lane];
+      A.part[((size_t)(A.nh - 1 - jj) * A.nblk + blockIdx.x) * 32 + lane] = t;
+    }
+  }
+}
+// db_j[n] = sum over blocks of part[j][b][n]: block j, 8 groups of 32 lanes each add every 8th partial, fixed order
+__global__ __launch_bounds__(256) void rr_policy_colsum_kernel(const RRPolBwdArgs A) {
+  __shared__ float sh[8][32];
+  const int j = blockIdx.x, lane = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const float* part = A.part + (size_t)j * A.nblk * 32;
+  float t = 0.0f;
+  for (int b = rg; b < A.nblk; b += 8) t += part[(size_t)b * 32 + lane];
+  sh[rg][lane] = t;
+  __syncthreads();
+  if (rg == 0) {
+    float u = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) u += sh[r][lane];
+    A.bgrad[j][lane] = u;
+  }
+}

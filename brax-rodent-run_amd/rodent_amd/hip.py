@@ -49,7 +49,7 @@ class RRPpoCfg(C.Structure):
 
 EXPORTS = ["rr_model_load", "rr_model_dims", "rr_model_set_solver", "rr_model_set_solver_type", "rr_model_destroy", "rr_model_table", "rr_kernarg_layout", "rr_batch_create",
            "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset", "rr_pipeline_step_to", "rr_env_step_to",
-           "rr_compute_gae", "rr_mlp_forward", "rr_ppo_loss_workspace_bytes", "rr_ppo_loss", "rr_policy_sample", "rr_mlp_silu_backward_workspace_bytes", "rr_mlp_silu_backward", "rr_mlp_value_backward_workspace_bytes", "rr_mlp_value_backward", "rr_mlp_weight_grad_workspace_bytes", "rr_mlp_weight_grad", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_schedule", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
+           "rr_compute_gae", "rr_mlp_forward", "rr_ppo_loss_workspace_bytes", "rr_ppo_loss", "rr_policy_sample", "rr_policy_backward_workspace_bytes", "rr_policy_backward", "rr_mlp_silu_backward_workspace_bytes", "rr_mlp_silu_backward", "rr_mlp_value_backward_workspace_bytes", "rr_mlp_value_backward", "rr_mlp_weight_grad_workspace_bytes", "rr_mlp_weight_grad", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_schedule", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
 
 _lib = None
 
@@ -90,6 +90,10 @@ def lib():
         L.rr_ppo_loss_workspace_bytes.restype = C.c_size_t
         L.rr_ppo_loss.argtypes = [C.c_void_p] * 9 + [C.c_int32] * 3 + [C.POINTER(RRPpoCfg)] + [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]
         L.rr_policy_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rr_policy_backward_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
+        L.rr_policy_backward_workspace_bytes.restype = C.c_size_t
+        L.rr_policy_backward.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                         C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t, C.c_void_p]
         L.rr_mlp_silu_backward_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
         L.rr_mlp_silu_backward_workspace_bytes.restype = C.c_size_t
         L.rr_mlp_silu_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -476,3 +480,30 @@ def policy_sample(logits, noise, min_std: float):
     _check(lib().rr_policy_sample(logits.data_ptr(), noise.data_ptr(), N, A, min_std, action.data_ptr(), raw.data_ptr(), lp.data_ptr(),
                                   C.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream)))
     return action, raw, lp
+
+
+def policy_backward(grad_logits, head_weight, hidden_weights, pre_act, bias_grads, bufs=None):
+    """Delta chain of the policy network's 32-wide hidden stack in one launch (C ABI `rr_policy_backward`).
+
+    grad_logits [M, P]; head_weight [P, 32]; hidden_weights: list, entry j >= 1 = W_j [32, 32] (entry 0 ignored); pre_act
+    [nh, >= M, 32] (rr_mlp_forward's policy_pre; the first M rows of each layer are overwritten by silu(z)); bias_grads: list of
+    nh [32] tensors.  Returns (delta [nh, M, 32], h = pre_act)."""
+    nh = pre_act.shape[0]
+    M, P = grad_logits.shape
+    if pre_act.shape[2] != 32 or pre_act.shape[1] < M or len(bias_grads) != nh or len(hidden_weights) != nh or head_weight.shape != (P, 32):
+        raise ValueError("rr_policy_backward: inconsistent shapes")
+    _ptr(grad_logits); _ptr(head_weight); _ptr(pre_act)
+    for j in range(nh):
+        _ptr(bias_grads[j], numel=32)
+        if j > 0:
+            _ptr(hidden_weights[j], numel=1024)
+    bufs = bufs if bufs is not None else {}
+    if bufs.get("pb_key") != (M, nh):
+        bufs["pb_ws"] = torch.empty((lib().rr_policy_backward_workspace_bytes(M, nh) + 3) // 4, device=pre_act.device)
+        bufs["pb_delta"] = torch.empty(nh, M, 32, device=pre_act.device)
+        bufs["pb_key"] = (M, nh)
+    wt = (C.c_void_p * nh)(*[hidden_weights[j].data_ptr() if j > 0 else None for j in range(nh)])
+    bg = (C.c_void_p * nh)(*[b.data_ptr() for b in bias_grads])
+    _check(lib().rr_policy_backward(grad_logits.data_ptr(), head_weight.data_ptr(), wt, nh, M, P, pre_act.data_ptr(), pre_act.shape[1], bufs["pb_delta"].data_ptr(), bg,
+                                    bufs["pb_ws"].data_ptr(), bufs["pb_ws"].numel() * 4, C.c_void_p(torch.cuda.current_stream(pre_act.device).cuda_stream)))
+    return bufs["pb_delta"], pre_act

@@ -2,19 +2,18 @@
 
 row indices of the minibatch inside the unroll buffer (no gathered copy of the observations) -> `rr_mlp_forward` (both networks, one f32-MFMA launch, pre-activations kept) ->
 `rr_ppo_loss` (GAE, normalised advantages, surrogate / value / entropy terms AND d loss / d network outputs, three launches) ->
-explicit backward (`rr_mlp_value_backward`: the value net's delta chain; `rr_mlp_silu_backward` for the 32-wide policy layers;
+explicit backward (`rr_mlp_value_backward` / `rr_policy_backward`: the delta chains of the two networks, one launch each;
 `rr_mlp_weight_grad`: every dW as a split-row matrix-core product) writing straight into the flat gradient buffer
 (`distributed.FlatGrads`).
 
 It computes what `losses.compute_ppo_loss` + `loss.backward()` compute [UP brax.training.agents.ppo.losses /
 brax.training.gradients; REF brax_rodent_run_ppo.py:97-114] -- `tests/test_gpu_ppo.py` holds the two paths
-against each other and against float64 -- with ~60 launches per minibatch instead of ~190 (no per-leaf gathers, no loss
+against each other and against float64 -- with ~40 launches per minibatch instead of ~190 (no per-leaf gathers, no loss
 elementwise chain, no autograd accumulation adds, no gradient zero fill).
 """
 from __future__ import annotations
 
 import torch
-import torch.nn.functional as F
 
 from .... import hip
 from ... import fused_mlp
@@ -33,18 +32,20 @@ class FusedUpdate:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
 
-    @staticmethod
-    def _policy_backward_into_grads(layers, pre, delta, obs, rows, mean, std):
-        """dW_l = delta_l' h_{l-1}, db_l = sum delta_l, delta_{l-1} = (delta_l W_l) * silu'(z_{l-1}), written into `.grad`.
-        `pre` (the forward's pre-activation dumps) is consumed: each z is overwritten by silu(z)."""
-        torch.sum(delta, 0, out=layers[-1].bias.grad)
-        for l in range(len(layers) - 1, 0, -1):
-            W = layers[l].weight
-            # one launch: delta_{l-1} over the product, h_{l-1} over z_{l-1}, db_{l-1}
-            nxt, h = hip.mlp_silu_backward(delta @ W, pre[l - 1], layers[l - 1].bias.grad)
-            hip.mlp_weight_grad(delta, h, W.grad)
-            delta = nxt
-        hip.mlp_weight_grad(delta, obs, layers[0].weight.grad, rows=rows, mean=mean, std=std, delta_colsum=layers[0].bias.grad)
+    def _policy_backward_into_grads(self, pre, g, obs, rows, mean, std):
+        """Policy network: the delta chain of the 32-wide stack is one launch (`rr_policy_backward`: delta_j, h_j = silu(z_j) over the
+        forward's dump, bias gradients); the weight gradients are split-row products of its outputs.  g [n, P] covers the first n
+        rows of the minibatch (the bootstrap rows behind them carry no policy gradient)."""
+        layers = self.policy_net.layers
+        nh = len(layers) - 1
+        n = g.shape[0]
+        delta, h = hip.policy_backward(g, layers[nh].weight, [None] + [layers[j].weight for j in range(1, nh)], pre,
+                                       [layers[j].bias.grad for j in range(nh)], self.bufs)
+        torch.sum(g, 0, out=layers[nh].bias.grad)
+        hip.mlp_weight_grad(g, h[nh - 1, :n], layers[nh].weight.grad)
+        for j in range(nh - 1, 0, -1):
+            hip.mlp_weight_grad(delta[j], h[j - 1, :n], layers[j].weight.grad)
+        hip.mlp_weight_grad(delta[0], obs, layers[0].weight.grad, rows=rows, mean=mean, std=std, delta_colsum=layers[0].bias.grad)
 
     def _value_backward_into_grads(self, pre, g, obs, rows, mean, std):
         """Value network: the delta chain (dX products, silu', h = silu(z), bias gradients) is ONE matrix-core launch
@@ -74,6 +75,6 @@ class FusedUpdate:
         noise = torch.randn(T * B, A, device=obs.device, dtype=obs.dtype, generator=generator)     # the draw of dist.entropy
         g_pol, g_val, metrics = hip.ppo_loss(pol, val, data, idx, noise, T, out=self.bufs, **self.cfg)
         n = T * B                                                                           # the bootstrap rows carry no policy gradient
-        self._policy_backward_into_grads(self.policy_net.layers, ppre[:, :n], g_pol[:n], obs, rows[:n], mean, std)
+        self._policy_backward_into_grads(ppre, g_pol[:n], obs, rows[:n], mean, std)
         self._value_backward_into_grads(vpre, g_val, obs, rows, mean, std)
         return {"total_loss": metrics[0], "policy_loss": metrics[1], "v_loss": metrics[2], "entropy_loss": metrics[3]}

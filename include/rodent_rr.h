@@ -185,6 +185,18 @@ int rr_ppo_loss(const float* policy_logits, const float* values, const float* ra
 int rr_policy_sample(const float* logits, const float* noise, int32_t N, int32_t A, float min_std, float* action, float* raw_action,
                      float* log_prob, void* stream);
 
+/* Backward pass of the policy network's hidden stack (32-wide SiLU layers) in one launch: delta_{nh-1} = (g W_head) *
+ * silu'(z_{nh-1}), delta_{j-1} = (delta_j W_j) * silu'(z_{j-1}).  grad_logits [M][P] (P <= 64) = d loss / d logits; head_weight
+ * [P][32]; hidden_weights: HOST array of nhidden device pointers, entry j (1 <= j < nhidden) = W_j [32 out][32 in]
+ * (torch.nn.Linear.weight), entry 0 unused; pre_act [nhidden][pre_act_rows >= M][32] = rr_mlp_forward's policy_pre, rows 0..M-1 of
+ * each layer overwritten by silu(z) (a minibatch may carry bootstrap rows, which have no policy gradient, behind the M used ones);
+ * delta [nhidden][M][32] out; bias_grads: HOST array of nhidden device pointers, db_j [32] (fixed-order sums).  The weight
+ * gradients (rr_mlp_weight_grad on these outputs) stay with the caller. */
+size_t rr_policy_backward_workspace_bytes(int32_t M, int32_t nhidden);
+int rr_policy_backward(const float* grad_logits, const float* head_weight, const float* const* hidden_weights, int32_t nhidden, int32_t M,
+                       int32_t P, float* pre_act, int32_t pre_act_rows, float* delta, float* const* bias_grads, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
 /* Elementwise half of the backward pass of one hidden SiLU layer of the networks above (the matrix products stay with the
  * caller): with g = delta_l W_l [M][H] and the layer's pre-activations z [M][H] (rr_mlp_forward's dumps),
  * delta = g * silu'(z), h = silu(z) (the operand of dW_l = delta_l' h) and bias_grad[n] = sum_m delta[m][n], in one pass

@@ -235,3 +235,41 @@ def test_policy_sample_kernel_matches_the_distribution():
     err, err32 = (lp.double().cpu() - lp64).abs().max(), (lp32 - lp64).abs().max()
     print(f"log_prob: kernel {err:.2e}  composed float32 {err32:.2e}  (|log_prob| up to {lp64.abs().max():.1f})")
     assert err <= 3 * err32 + 1e-5
+
+
+@pytest.mark.parametrize("M,extra,P", [(20480, 2048, 60), (333, 0, 60), (50, 7, 2)])
+def test_policy_backward_chain_kernel(M, extra, P):
+    """rr_policy_backward against float64: delta_j, h_j = silu(z_j), db_j of the 32-wide stack; rows behind the first M of each
+    layer (the bootstrap rows of a minibatch) are left alone."""
+    from rodent_amd import hip
+    nh, H = 4, 32
+    g = torch.Generator().manual_seed(M + P)
+    z = torch.randn(nh, M + extra, H, generator=g) * 1.5
+    Ws = [None] + [torch.randn(H, H, generator=g) / 5 for _ in range(1, nh)]
+    wh = torch.randn(P, H, generator=g) / 5
+    gl = torch.randn(M, P, generator=g)
+
+    def chain(dt, dev):
+        c = lambda x: x.to(dt).to(dev)
+        zz = c(z[:, :M])
+        s = torch.sigmoid(zz)
+        sp, hh = s * (1 + zz * (1 - s)), zz * s
+        d = [None] * nh
+        d[nh - 1] = (c(gl) @ c(wh)) * sp[nh - 1]
+        for j in range(nh - 1, 0, -1):
+            d[j - 1] = (d[j] @ c(Ws[j])) * sp[j - 1]
+        return torch.stack(d).double().cpu(), hh.double().cpu()
+    d64, h64 = chain(torch.float64, "cpu")
+    d32, _ = chain(torch.float32, DEV)
+    pre = z.to(DEV).contiguous()
+    bgs = [torch.empty(H, device=DEV) for _ in range(nh)]
+    delta, h = hip.policy_backward(gl.to(DEV), wh.to(DEV), [None] + [Ws[j].to(DEV) for j in range(1, nh)], pre, bgs)
+    torch.cuda.synchronize()
+    assert (h[:, :M].double().cpu() - h64).abs().max() <= 2e-6 * h64.abs().max()
+    assert torch.equal(h[:, M:].cpu(), z[:, M:])                                   # untouched
+    for j in range(nh):
+        scale = d64[j].abs().max()
+        err, err32 = (delta[j].double().cpu() - d64[j]).abs().max() / scale, (d32[j] - d64[j]).abs().max() / scale
+        print(f"M={M} layer {j}: policy chain {err:.2e}  torch-f32 {err32:.2e}")
+        assert err <= 3 * err32 + 2e-6, (j, float(err), float(err32))
+        assert (bgs[j].double().cpu() - d64[j].sum(0)).abs().max() <= 3e-5 * d64[j].abs().sum(0).max(), j
