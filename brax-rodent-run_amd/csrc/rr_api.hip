@@ -472,7 +472,7 @@ extern "C" int rr_policy_sample(const float* logits, const float* noise, int32_t
 }
 
 // policy network backward: the delta chain of the 32-wide stack in one launch (csrc/rr_ppo.h)
-static int pol_bwd_blocks(int M) { return std::max(1, std::min(1024, (M + 7) / 8)); }
+static int pol_bwd_blocks(int M) { return std::max(1, std::min(256, (M + 7) / 8)); }     // one block per CU: the weights are staged once per block, the bias reduction reads 256 partials
 extern "C" size_t rr_policy_backward_workspace_bytes(int32_t M, int32_t nhidden) {
   if (M <= 0 || nhidden <= 0) return 0;
   return (size_t)nhidden * pol_bwd_blocks(M) * 32 * sizeof(float);
