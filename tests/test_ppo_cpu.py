@@ -158,3 +158,24 @@ def test_training_state_is_carried():
     assert ts.env_steps.dtype == torch.int32 and int(ts.env_steps) == 16 * 5 * 2 * 3
     assert float(ts.normalizer_params.count) == 16 * 5 * 2 * 3
     assert ts.params.policy is out[1][1] and len(ts.optimizer_state.state) > 0
+
+
+def test_state_pytree_helpers_of_the_graph_replay():
+    """envs.graphed.tree_leaves / tree_map (used to keep a state pytree in fixed buffers across HIP-graph replays): order, aliases,
+    None leaves, nested containers."""
+    import dataclasses
+    from rodent_amd.envs import graphed
+
+    @dataclasses.dataclass
+    class S:
+        a: torch.Tensor
+        b: dict
+        c: object = None
+
+    x = torch.arange(3.0)
+    s = S(a=x, b={"k": [x, torch.ones(2)], "n": None}, c=(torch.zeros(1),))
+    leaves = graphed.tree_leaves(s)
+    assert [tuple(t.shape) for t in leaves] == [(3,), (3,), (2,), (1,)] and leaves[0] is leaves[1]
+    t = graphed.tree_map(lambda v: v + 1, s)
+    assert isinstance(t, S) and t.b["n"] is None and isinstance(t.c, tuple) and torch.equal(t.b["k"][1], torch.full((2,), 2.0))
+    assert torch.equal(graphed.tree_leaves(t)[0], x + 1)
