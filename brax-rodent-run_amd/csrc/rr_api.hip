@@ -566,6 +566,40 @@ extern "C" int rr_mlp_forward(const float* obs, const int64_t* obs_rows, int32_t
   return RR_OK;
 }
 
+// the rollout's actor in two launches: first policy layer split over k, then the remaining layers + the tanh-normal head
+#define RR_POL_KSLICES 8
+extern "C" size_t rr_policy_act_workspace_bytes(int32_t M) { return M > 0 ? (size_t)RR_POL_KSLICES * M * RR_MLP_PH * sizeof(float) : 0; }
+extern "C" int rr_policy_act(const float* obs, const int64_t* obs_rows, int32_t M, int32_t K, const float* mean, const float* std_,
+                             const rr_mlp_net* policy, const float* noise, float min_std, float* action, float* raw_action, float* log_prob,
+                             float* logits, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!obs || !policy || !action || !workspace || M <= 0 || K <= 0) return fail(RR_EINVAL, "rr_policy_act: bad argument");
+  if ((mean == nullptr) != (std_ == nullptr)) return fail(RR_EINVAL, "rr_policy_act: mean and std must be given together");
+  RRMlpNet net;
+  int rc = mlp_net(policy, K, RR_MLP_PH, false, &net, "policy");
+  if (rc) return rc;
+  const int nh = net.nlayers - 1, P = net.out_dim, A_ = P / 2;
+  if ((P & 1) || A_ > 32 || nh > RR_POL_MAXL - 1) return fail(RR_EUNSUPPORTED, "rr_policy_act: the head must be 2 x action_size <= 64 wide");
+  if (workspace_bytes < rr_policy_act_workspace_bytes(M)) return fail(RR_EINVAL, "rr_policy_act: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  RRPolL1Args L;
+  memset(&L, 0, sizeof(L));
+  L.obs = obs; L.rows = obs_rows; L.mean = mean; L.std_ = std_; L.W = net.W[0]; L.M = M; L.K = K; L.part = (float*)workspace;
+  const int nchunk = (K + RR_MLP_KC - 1) / RR_MLP_KC;
+  L.chunks_per_slice = (nchunk + RR_POL_KSLICES - 1) / RR_POL_KSLICES;
+  const int nslice = (nchunk + L.chunks_per_slice - 1) / L.chunks_per_slice;
+  hipLaunchKernelGGL(rr_policy_l1_kernel, dim3((M + RR_MLP_BM - 1) / RR_MLP_BM, nslice), dim3(256), 0, st, L);
+  RRPolTailArgs T;
+  memset(&T, 0, sizeof(T));
+  T.part = (const float*)workspace; T.nslice = nslice; T.M = M; T.P = P; T.A = A_; T.nh = nh; T.noise = noise; T.min_std = min_std;
+  T.action = action; T.raw = raw_action; T.logp = log_prob; T.logits = logits;
+  for (int l = 1; l <= nh; ++l) T.W[l] = net.W[l];
+  for (int l = 0; l <= nh; ++l) T.b[l] = net.b[l];
+  const size_t lds = ((size_t)(nh - 1) * 1024 + 2048 + (size_t)nh * 32 + 64) * sizeof(float);
+  hipLaunchKernelGGL(rr_policy_tail_kernel, dim3(std::max(1, std::min(256, (M + 7) / 8))), dim3(256), lds, st, T);
+  HIPCHK(hipGetLastError());
+  return RR_OK;
+}
+
 // value network backward: the delta chain on the matrix cores (csrc/rr_mlp.h)
 extern "C" size_t rr_mlp_value_backward_workspace_bytes(int32_t M, int32_t nhidden) {
   if (M <= 0 || nhidden <= 0) return 0;

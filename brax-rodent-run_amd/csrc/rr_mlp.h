@@ -606,3 +606,77 @@ __global__ __launch_bounds__(256) void rr_mlp_dw_reduce_kernel(const RRDwArgs A)
     A.out[e] = u;
   }
 }
+
+// ------------------------------------------------------------------------------------------ the rollout's actor: policy net + head, two launches
+// The actor step between two env steps is [N x 1263] -> 32 x4 -> 2A at N = 2048: 0.17 GFLOP and 10 MB -- microseconds of work -- but as a
+// row-tiled kernel it is 64 workgroups walking 79 k-chunks one after the other (~70 us).  Here the first layer is split over k as well:
+// rr_policy_l1_kernel, grid (N / 32, KS), each workgroup 32 rows x one k-slice on v_mfma_f32_16x16x4_f32, partial sums [KS][N][32];
+// rr_policy_tail_kernel (csrc/rr_ppo.h side: 32 lanes per row, weights in LDS) adds the slices in order, applies the remaining layers
+// and the tanh-normal head (sample, squash, log-prob) or its mode.
+struct RRPolL1Args {
+  const float* obs; const int64_t* rows; const float* mean; const float* std_; const float* W;    // W [32][K]
+  int M, K, chunks_per_slice;
+  float* part;                     // [gridDim.y][M][32]
+};
+__global__ __launch_bounds__(256) void rr_policy_l1_kernel(const RRPolL1Args A) {
+  __shared__ __attribute__((aligned(16))) float sX[RR_MLP_BM * RR_SX], sW[RR_MLP_PH * RR_SX];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int row0 = blockIdx.x * RR_MLP_BM, M = A.M, K = A.K;
+  const int nchunk = (K + RR_MLP_KC - 1) / RR_MLP_KC;
+  const int c0 = blockIdx.y * A.chunks_per_slice, c1 = min(nchunk, c0 + A.chunks_per_slice);
+  typedef RRStage<RR_MLP_BM> St;     // 32 rows x 16: 128 pieces, threads 0..127
+  St gx, gw;
+  rr_f4 mu[St::PER], sd[St::PER];
+  long long xoff[St::PER];
+#pragma unroll
+  for (int i = 0; i < St::PER; ++i) {
+    const int v = min((int)threadIdx.x + 256 * i, St::NV - 1), m = min(row0 + (v >> 2), M - 1);
+    xoff[i] = (long long)(A.rows ? A.rows[m] : m) * K;
+  }
+  auto fetch_t = [&](int c, auto full) {
+    constexpr bool FULL = decltype(full)::value;
+    const int k0 = c * RR_MLP_KC;
+    gx.template fetch_at<FULL>(A.obs, xoff, k0, K);
+    gw.template fetch<FULL>(A.W, K, 0, RR_MLP_PH, k0, K);
+    if (A.mean) {
+#pragma unroll
+      for (int i = 0; i < St::PER; ++i) {
+        const int k = k0 + 4 * ((threadIdx.x + 256 * i) & 3);
+        mu[i] = St::template load4<FULL>(A.mean, k, K);
+        sd[i] = St::template load4<FULL>(A.std_, k, K);
+        if (!FULL) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) sd[i][j] = k + j < K ? sd[i][j] : 1.0f;
+        }
+      }
+    }
+  };
+  auto fetch = [&](int c) {
+    if ((c + 1) * RR_MLP_KC <= K) fetch_t(c, std::true_type{});
+    else fetch_t(c, std::false_type{});
+  };
+  rr_f16 d0 = {0}, d1 = {0};
+  rr_f4 ap = {0, 0, 0, 0};
+  if (c0 < c1) fetch(c0);
+  for (int c = c0; c < c1; ++c) {
+    if (A.mean) {
+#pragma unroll
+      for (int i = 0; i < St::PER; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gx.r[i][j] = (gx.r[i][j] - mu[i][j]) / sd[i][j];
+    }
+    gx.commit(sX);
+    gw.commit(sW);
+    __syncthreads();
+    if (c + 1 < c1) fetch(c + 1);
+    rr_mlp_chunk<false, true>(sX, RR_SX, 0, sW, 0, d0, d1, ap, lane, wv);
+    __syncthreads();
+  }
+  const int mt = wv >> 1, nt = wv & 1, n = 16 * nt + (lane & 15);
+  float* dst = A.part + (size_t)blockIdx.y * M * RR_MLP_PH;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = row0 + 16 * mt + 4 * (lane >> 4) + r;
+    if (m < M) dst[(size_t)m * RR_MLP_PH + n] = ap[r];
+  }
+}

@@ -330,3 +330,71 @@ __global__ __launch_bounds__(256) void rr_policy_colsum_kernel(const RRPolBwdArg
     A.bgrad[j][lane] = u;
   }
 }
+
+// ------------------------------------------------------------------------------------------ the rollout's actor, second launch
+// Rows of the policy's first-layer partial sums (rr_policy_l1_kernel, csrc/rr_mlp.h) -> action.  32 lanes per row (lane = hidden unit),
+// weights TRANSPOSED in LDS (lane n reads w[k][n]: consecutive banks), the activation vector handed around by shuffles:
+//   h = silu(sum_slices + b_0); h = silu(W_l h + b_l), l = 1 .. nh-1; logits = W_head h + b_head;
+//   noise given: raw = loc + (softplus(s) + min_std) eps, action = tanh(raw), log_prob as rr_policy_sample_kernel; noise NULL: tanh(loc).
+struct RRPolTailArgs {
+  const float* part; int nslice;
+  const float* W[RR_POL_MAXL];    // W[l], l = 1 .. nh-1: [32][32];  W[nh]: head [P][32]
+  const float* b[RR_POL_MAXL + 1];// b[0 .. nh-1]: [32]; b[nh]: [P]
+  int M, P, A, nh;
+  const float* noise; float min_std;
+  float* action; float* raw; float* logp; float* logits;     // raw / logp / logits nullable
+};
+__global__ __launch_bounds__(256) void rr_policy_tail_kernel(const RRPolTailArgs T) {
+  extern __shared__ float sw[];                      // (nh - 1) x [32 k][32 n], then head [32 k][64 n], then biases nh x 32 + 64
+  const int lane = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  float* swh = sw + (T.nh - 1) * 1024;
+  float* sb = swh + 2048;
+  for (int l = 1; l < T.nh; ++l)
+    for (int e = threadIdx.x; e < 1024; e += 256) sw[(l - 1) * 1024 + (e & 31) * 32 + (e >> 5)] = T.W[l][e];      // [n][k] -> [k][n]
+  for (int e = threadIdx.x; e < 2048; e += 256) { const int n = e >> 5, k = e & 31; swh[k * 64 + n] = n < T.P ? T.W[T.nh][n * 32 + k] : 0.0f; }
+  for (int e = threadIdx.x; e < T.nh * 32; e += 256) sb[e] = T.b[e >> 5][e & 31];
+  for (int e = threadIdx.x; e < 64; e += 256) sb[T.nh * 32 + e] = e < T.P ? T.b[T.nh][e] : 0.0f;
+  __syncthreads();
+  const float HALF_LOG_2PI = 0.91893853320467274178f, LOG2 = 0.69314718055994530942f;
+  for (int row = blockIdx.x * 8 + rg; row < T.M; row += gridDim.x * 8) {
+    float z = sb[lane];
+    for (int s = 0; s < T.nslice; ++s) z += T.part[((size_t)s * T.M + row) * 32 + lane];
+    float h = z / (1.0f + expf(-z));
+    for (int l = 1; l < T.nh; ++l) {
+      const float* w = sw + (l - 1) * 1024;
+      float acc = sb[l * 32 + lane];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) acc = fmaf(__shfl(h, k, 32), w[k * 32 + lane], acc);
+      h = acc / (1.0f + expf(-acc));
+    }
+    float o0 = sb[T.nh * 32 + lane], o1 = sb[T.nh * 32 + 32 + lane];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { const float hk = __shfl(h, k, 32); o0 = fmaf(hk, swh[k * 64 + lane], o0); o1 = fmaf(hk, swh[k * 64 + 32 + lane], o1); }
+    if (T.logits) {
+      if (lane < T.P) T.logits[(size_t)row * T.P + lane] = o0;
+      if (lane + 32 < T.P) T.logits[(size_t)row * T.P + 32 + lane] = o1;
+    }
+    // lane a needs logits[a] (its own o0) and logits[A + a]: o0 of lane A + a, or o1 of lane A + a - 32
+    const float s_lo = __shfl(o0, (T.A + lane) & 31, 32), s_hi = __shfl(o1, (T.A + lane - 32) & 31, 32);
+    const float sraw = T.A + lane < 32 ? s_lo : s_hi;
+    float lp = 0.0f;
+    if (lane < T.A) {
+      const float loc = o0;
+      if (T.noise) {
+        const float scale = rr_softplus(sraw) + T.min_std;
+        const float eps = T.noise[(size_t)row * T.A + lane], raw = loc + scale * eps;
+        const float zz = (raw - loc) / scale;
+        lp = -0.5f * zz * zz - logf(scale) - HALF_LOG_2PI - 2.0f * (LOG2 - raw - rr_softplus(-2.0f * raw));
+        if (T.raw) T.raw[(size_t)row * T.A + lane] = raw;
+        T.action[(size_t)row * T.A + lane] = tanhf(raw);
+      } else {
+        T.action[(size_t)row * T.A + lane] = tanhf(loc);
+      }
+    }
+    if (T.noise && T.logp) {
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) lp += __shfl_xor(lp, o, 32);
+      if (lane == 0) T.logp[row] = lp;
+    }
+  }
+}

@@ -49,7 +49,7 @@ class RRPpoCfg(C.Structure):
 
 EXPORTS = ["rr_model_load", "rr_model_dims", "rr_model_set_solver", "rr_model_set_solver_type", "rr_model_destroy", "rr_model_table", "rr_kernarg_layout", "rr_batch_create",
            "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset", "rr_pipeline_step_to", "rr_env_step_to",
-           "rr_compute_gae", "rr_mlp_forward", "rr_ppo_loss_workspace_bytes", "rr_ppo_loss", "rr_policy_sample", "rr_policy_backward_workspace_bytes", "rr_policy_backward", "rr_mlp_silu_backward_workspace_bytes", "rr_mlp_silu_backward", "rr_mlp_value_backward_workspace_bytes", "rr_mlp_value_backward", "rr_mlp_weight_grad_workspace_bytes", "rr_mlp_weight_grad", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_schedule", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
+           "rr_compute_gae", "rr_mlp_forward", "rr_ppo_loss_workspace_bytes", "rr_ppo_loss", "rr_policy_act_workspace_bytes", "rr_policy_act", "rr_policy_sample", "rr_policy_backward_workspace_bytes", "rr_policy_backward", "rr_mlp_silu_backward_workspace_bytes", "rr_mlp_silu_backward", "rr_mlp_value_backward_workspace_bytes", "rr_mlp_value_backward", "rr_mlp_weight_grad_workspace_bytes", "rr_mlp_weight_grad", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_schedule", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
 
 _lib = None
 
@@ -89,6 +89,10 @@ def lib():
         L.rr_ppo_loss_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
         L.rr_ppo_loss_workspace_bytes.restype = C.c_size_t
         L.rr_ppo_loss.argtypes = [C.c_void_p] * 9 + [C.c_int32] * 3 + [C.POINTER(RRPpoCfg)] + [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]
+        L.rr_policy_act_workspace_bytes.argtypes = [C.c_int32]
+        L.rr_policy_act_workspace_bytes.restype = C.c_size_t
+        L.rr_policy_act.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(RRMlpNet), C.c_void_p, C.c_float,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.rr_policy_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rr_policy_backward_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
         L.rr_policy_backward_workspace_bytes.restype = C.c_size_t
@@ -507,3 +511,37 @@ def policy_backward(grad_logits, head_weight, hidden_weights, pre_act, bias_grad
     _check(lib().rr_policy_backward(grad_logits.data_ptr(), head_weight.data_ptr(), wt, nh, M, P, pre_act.data_ptr(), pre_act.shape[1], bufs["pb_delta"].data_ptr(), bg,
                                     bufs["pb_ws"].data_ptr(), bufs["pb_ws"].numel() * 4, C.c_void_p(torch.cuda.current_stream(pre_act.device).cuda_stream)))
     return bufs["pb_delta"], pre_act
+
+
+_pa_ws = {}
+
+
+def policy_act(obs, mean, std, policy, noise, min_std: float, want_logits: bool = False, rows=None):
+    """The rollout's actor step in two launches (C ABI `rr_policy_act`): obs [M, K] (or obs[rows]) -> normalise -> policy MLP ->
+    tanh-normal head.  noise [M, A] or None (deterministic: action = tanh(loc)).  Returns (action, raw_action | None,
+    log_prob | None, logits | None)."""
+    M, K = obs.shape
+    _ptr(obs)
+    if rows is not None:
+        M = rows.numel()
+        _ptr(rows, torch.int64)
+    pn, keep = _mlp_net(*policy)
+    A = policy[0][-1].shape[0] // 2
+    dev = obs.device
+    action = torch.empty(M, A, device=dev)
+    raw = lp = logits = None
+    if noise is not None:
+        _ptr(noise, numel=M * A)
+        raw, lp = torch.empty(M, A, device=dev), torch.empty(M, device=dev)
+    if want_logits:
+        logits = torch.empty(M, 2 * A, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    key = (dev, M, stream)                 # per stream: sub-batches on several streams run this concurrently
+    if key not in _pa_ws:
+        _pa_ws[key] = torch.empty((lib().rr_policy_act_workspace_bytes(M) + 3) // 4, device=dev)
+    ws = _pa_ws[key]
+    p = lambda t: t.data_ptr() if t is not None else None
+    _check(lib().rr_policy_act(obs.data_ptr(), p(rows), M, K, _ptr(mean, numel=K) if mean is not None else None,
+                               _ptr(std, numel=K) if std is not None else None, C.byref(pn), p(noise), min_std, action.data_ptr(), p(raw), p(lp),
+                               p(logits), ws.data_ptr(), ws.numel() * 4, C.c_void_p(stream)))
+    return action, raw, lp, logits

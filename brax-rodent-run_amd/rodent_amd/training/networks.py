@@ -107,8 +107,19 @@ def make_inference_fn(ppo_networks: PPONetworks):
         dist = ppo_networks.parametric_action_distribution
         fused = os.environ.get("RR_FUSED_MLP", "1") == "1" and fused_mlp.fusable(net, fused_mlp.POLICY_HIDDEN, 64)
 
+        two_launch = (fused and isinstance(dist, NormalTanhDistribution) and type(dist) is NormalTanhDistribution and dist.event_size <= 32
+                      and os.environ.get("RR_POLICY_ACT", "1") == "1")
+
         @torch.no_grad()
         def policy(observations, key_sample=None):
+            if two_launch and observations.is_cuda and observations.dtype == torch.float32 and observations.dim() == 2:
+                # the whole actor step (normalise, policy MLP with the first layer split over k, tanh-normal head) in two launches
+                from .. import hip
+                mean, std = (None, None) if normalizer_params is None else (normalizer_params.mean, normalizer_params.std)
+                eps = None if deterministic else torch.randn(observations.shape[0], dist.event_size, device=observations.device,
+                                                              dtype=observations.dtype, generator=key_sample)
+                action, raw, lp, _ = hip.policy_act(observations.contiguous(), mean, std, fused_mlp.net_params(net), eps, dist.min_std)
+                return (action, {}) if deterministic else (action, {"log_prob": lp, "raw_action": raw})
             if fused and observations.is_cuda and observations.dtype == torch.float32 and observations.dim() == 2:
                 mean, std = (None, None) if normalizer_params is None else (normalizer_params.mean, normalizer_params.std)
                 logits = fused_mlp.policy_logits(observations, mean, std, net)        # normalise + MLP: one MFMA launch

@@ -178,6 +178,17 @@ int rr_ppo_loss(const float* policy_logits, const float* values, const float* ra
                 const rr_ppo_cfg* cfg, float* grad_logits, float* grad_values, float* metrics, void* workspace, size_t workspace_bytes,
                 void* stream);
 
+/* The rollout's actor step, acting.actor_step -> make_inference_fn [UP; SURVEY.md a22], in two launches: observations (optionally
+ * through obs_rows, optionally normalised by mean / std) -> policy network (as rr_mlp_forward takes it: 32-wide hidden layers,
+ * head 2 x action_size <= 64) -> tanh-normal head.  noise [M][A] standard normal draws: raw_action = loc + (softplus(scale) + min_std)
+ * * noise, action = tanh(raw_action), log_prob [M]; noise NULL: the deterministic policy, action = tanh(loc).  raw_action, log_prob,
+ * logits [M][2A] are optional outputs (NULL = not written).  The first layer is split over the observation width across
+ * workgroups (the batch alone is 64 row tiles for 256 CUs).  workspace: rr_policy_act_workspace_bytes(M) bytes of device memory. */
+size_t rr_policy_act_workspace_bytes(int32_t M);
+int rr_policy_act(const float* obs, const int64_t* obs_rows, int32_t M, int32_t K, const float* mean, const float* std,
+                  const rr_mlp_net* policy, const float* noise, float min_std, float* action, float* raw_action, float* log_prob,
+                  float* logits, void* workspace, size_t workspace_bytes, void* stream);
+
 /* The actor's head on the rollout path, `NormalTanhDistribution` of brax.training.distribution as acting.actor_step uses it [UP;
  * SURVEY.md a22]: logits [N][2A] = (loc | pre-softplus scale), noise [N][A] standard normal draws ->
  * raw_action = loc + (softplus(scale) + min_std) * noise, action = tanh(raw_action), log_prob [N] of raw_action under the

@@ -273,3 +273,43 @@ def test_policy_backward_chain_kernel(M, extra, P):
         print(f"M={M} layer {j}: policy chain {err:.2e}  torch-f32 {err32:.2e}")
         assert err <= 3 * err32 + 2e-6, (j, float(err), float(err32))
         assert (bgs[j].double().cpu() - d64[j].sum(0)).abs().max() <= 3e-5 * d64[j].abs().sum(0).max(), j
+
+
+@pytest.mark.parametrize("M,K,use_rows", [(2048, 1263, False), (1024, 1263, True), (100, 333, False), (1, 1263, False)])
+def test_policy_act_two_launches(M, K, use_rows):
+    """rr_policy_act (first layer split over k + tail kernel with the tanh-normal head) against the float64 policy; the float32
+    nn.Linear policy is the yardstick.  Stochastic and deterministic modes, optional row indirection."""
+    import copy
+    from rodent_amd import hip
+    from rodent_amd.training import fused_mlp, networks
+    torch.manual_seed(M + K)
+    A = 30
+    nets = networks.make_ppo_networks(K, A, device=DEV)
+    net, dist = nets.policy_network, nets.parametric_action_distribution
+    for l in net.layers:
+        l.bias.data.uniform_(-0.2, 0.2)
+    R = M + 50 if use_rows else M
+    obs = torch.randn(R, K, device=DEV) * 2 + 0.3
+    rows = torch.randperm(R, device=DEV)[:M] if use_rows else None
+    mean, std = torch.randn(K, device=DEV) * 0.3, torch.rand(K, device=DEV) + 0.5
+    eps = torch.randn(M, A, device=DEV)
+    x = obs[rows] if use_rows else obs
+    net64 = copy.deepcopy(net).double()
+    lg64 = net64((x.double() - mean.double()) / std.double())
+    lg32 = net((x - mean) / std).double()
+    loc, scale = dist._params(lg64)
+    raw64 = loc + scale * eps.double()
+    lp64 = dist.log_prob(lg64, raw64)
+    act, raw, lp, lg = hip.policy_act(obs, mean, std, fused_mlp.net_params(net), eps, dist.min_std, want_logits=True, rows=rows)
+    torch.cuda.synchronize()
+    scale_l = lg64.abs().max()
+    err, err32 = (lg.double() - lg64).abs().max() / scale_l, (lg32 - lg64).abs().max() / scale_l
+    print(f"M={M} K={K}: logits two-launch {float(err):.2e}  nn.Linear f32 {float(err32):.2e}")
+    assert err <= 3 * err32 + 2e-6
+    tol = 20 * float(err.clamp_min(1e-7)) * float(scale_l)                      # what the logits' error can do to the head's outputs
+    assert (raw.double() - raw64).abs().max() <= tol + 1e-5
+    assert (act.double() - torch.tanh(raw64)).abs().max() <= tol + 1e-5
+    assert (lp.double() - lp64).abs().max() <= 50 * tol + 1e-4
+    act_d, raw_d, lp_d, _ = hip.policy_act(obs, mean, std, fused_mlp.net_params(net), None, dist.min_std, rows=rows)
+    assert raw_d is None and lp_d is None
+    assert (act_d.double() - torch.tanh(loc)).abs().max() <= tol + 1e-5

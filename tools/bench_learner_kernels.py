@@ -55,3 +55,11 @@ with torch.no_grad():
     t = timeit(lambda: hip.mlp_forward(obs[:2048], mean, std, pp))
     out["rollout_policy_forward_ms"] = t
 print(json.dumps(out))
+with torch.no_grad():
+    eps = torch.randn(2048, 30, device=dev)
+    t = timeit(lambda: hip.policy_act(obs[:2048], mean, std, pp, eps, 0.001))
+    def old():
+        lg = hip.mlp_forward(obs[:2048], mean, std, pp)[0]
+        return hip.policy_sample(lg, eps, 0.001)
+    t0 = timeit(old)
+print(json.dumps({"rollout_actor_two_launch_ms": t, "rollout_actor_forward_plus_sample_ms": t0}))
