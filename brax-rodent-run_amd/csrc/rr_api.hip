@@ -472,7 +472,7 @@ extern "C" int rr_policy_sample(const float* logits, const float* noise, int32_t
 }
 
 // policy network backward: the delta chain of the 32-wide stack in one launch (csrc/rr_ppo.h)
-static int pol_bwd_blocks(int M) { return std::max(1, std::min(256, (M + 7) / 8)); }     // one block per CU: the weights are staged once per block, the bias reduction reads 256 partials
+static int pol_bwd_blocks(int M) { return std::max(1, std::min(1024, (M + 7) / 8)); }     // latency-bound per row: many small blocks (256 blocks: 76 us, 1024: 35 us)
 extern "C" size_t rr_policy_backward_workspace_bytes(int32_t M, int32_t nhidden) {
   if (M <= 0 || nhidden <= 0) return 0;
   return (size_t)nhidden * pol_bwd_blocks(M) * 32 * sizeof(float);
@@ -496,7 +496,7 @@ extern "C" int rr_policy_backward(const float* grad_logits, const float* head_we
   const size_t lds = ((size_t)P * 32 + (size_t)(nhidden - 1) * 1024) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(rr_policy_backward_kernel, dim3(A.nblk), dim3(256), lds, st, A);
-  hipLaunchKernelGGL(rr_policy_colsum_kernel, dim3(nhidden), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(rr_policy_colsum_kernel, dim3(nhidden), dim3(1024), 0, st, A);
   HIPCHK(hipGetLastError());
   return RR_OK;
 }

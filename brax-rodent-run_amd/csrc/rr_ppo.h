@@ -314,19 +314,19 @@ __global__ __launch_bounds__(256) void rr_policy_backward_kernel(const RRPolBwdA
     }
   }
 }
-// db_j[n] = sum over blocks of part[j][b][n]: block j, 8 groups of 32 lanes each add every 8th partial, fixed order
-__global__ __launch_bounds__(256) void rr_policy_colsum_kernel(const RRPolBwdArgs A) {
-  __shared__ float sh[8][32];
+// db_j[n] = sum over blocks of part[j][b][n]: block j, 32 groups of 32 lanes each add every 32nd partial, fixed order
+__global__ __launch_bounds__(1024) void rr_policy_colsum_kernel(const RRPolBwdArgs A) {
+  __shared__ float sh[32][32];
   const int j = blockIdx.x, lane = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const float* part = A.part + (size_t)j * A.nblk * 32;
   float t = 0.0f;
-  for (int b = rg; b < A.nblk; b += 8) t += part[(size_t)b * 32 + lane];
+  for (int b = rg; b < A.nblk; b += 32) t += part[(size_t)b * 32 + lane];
   sh[rg][lane] = t;
   __syncthreads();
   if (rg == 0) {
     float u = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) u += sh[r][lane];
+    for (int r = 0; r < 32; ++r) u += sh[r][lane];
     A.bgrad[j][lane] = u;
   }
 }

@@ -414,7 +414,7 @@ def mlp_silu_backward(g, z, bias_grad):
     M, H = g.shape
     _ptr(g); _ptr(z, numel=M * H); _ptr(bias_grad, numel=H)
     wb = lib().rr_mlp_silu_backward_workspace_bytes(M, H)
-    key = (g.device, M, H)
+    key = (g.device, M, H, torch.cuda.current_stream(g.device).cuda_stream)      # per stream: the workspace is scratch of the launch
     if key not in _silu_ws:
         _silu_ws[key] = torch.empty((wb + 3) // 4, device=g.device)
     ws = _silu_ws[key]
@@ -464,7 +464,7 @@ def mlp_weight_grad(delta, act, out, rows=None, mean=None, std=None, delta_colsu
         _ptr(rows, torch.int64, M)
     elif act.shape[0] < M:
         raise ValueError("rr_mlp_weight_grad: fewer activation rows than delta rows")
-    key = (delta.device, M, O, I)
+    key = (delta.device, M, O, I, torch.cuda.current_stream(delta.device).cuda_stream)      # per stream (scratch of the launch)
     if key not in _dw_ws:
         _dw_ws[key] = torch.empty((lib().rr_mlp_weight_grad_workspace_bytes(M, O, I) + 3) // 4, device=delta.device)
     ws = _dw_ws[key]

@@ -52,6 +52,19 @@ for S in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
                     g.replay()
         run(5 * R)
         torch.cuda.synchronize()
+        off = int(os.environ.get("RR_PROBE_OFFSET_CYCLES", "0"))
+        if off and S > 1:                       # start the sub-batches out of phase (stream s waits s * off spin cycles first)
+            for si, st in enumerate(streams):
+                with torch.cuda.stream(st):
+                    if si:
+                        t_a = torch.cuda.Event(enable_timing=True); t_b = torch.cuda.Event(enable_timing=True)
+                        t_a.record(); torch.cuda._sleep(si * off); t_b.record()
+            torch.cuda.synchronize()
+            print("sleep of", off, "cycles took", t_a.elapsed_time(t_b), "ms", flush=True)
+            for si, st in enumerate(streams):   # again, this time followed immediately by the timed replays
+                with torch.cuda.stream(st):
+                    if si:
+                        torch.cuda._sleep(si * off)
     t0 = time.perf_counter()
     run(STEPS)
     torch.cuda.synchronize()
