@@ -652,7 +652,7 @@ extern "C" size_t rr_mlp_weight_grad_workspace_bytes(int32_t M, int32_t O, int32
   return (size_t)dw_plan(M, O, I).nslice * O * I * sizeof(float);
 }
 template <int GO, int GI, int WO, int WI, int KC>
-static int dw_launch(const RRDwArgs& A, dim3 grid, hipStream_t st) {
+static int dw_launch(const RRDwBatch& B, dim3 grid, hipStream_t st) {
   constexpr int TO = GO * WO * 32, TI = GI * WI * 32;
   constexpr size_t lds = (size_t)KC * ((TO + (TO % 64 == 0 ? 32 : 0)) + (TI + (TI % 64 == 0 ? 32 : 0))) * sizeof(float);
   static bool attr_set = false;
@@ -660,32 +660,64 @@ static int dw_launch(const RRDwArgs& A, dim3 grid, hipStream_t st) {
     HIPCHK(hipFuncSetAttribute((const void*)rr_mlp_dw_kernel<GO, GI, WO, WI, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((rr_mlp_dw_kernel<GO, GI, WO, WI, KC>), grid, dim3(256), lds, st, A);
+  hipLaunchKernelGGL((rr_mlp_dw_kernel<GO, GI, WO, WI, KC>), grid, dim3(256), lds, st, B);
+  return RR_OK;
+}
+extern "C" size_t rr_mlp_weight_grad_batch_workspace_bytes(const rr_dw_item* items, int32_t n) {
+  size_t t = 0;
+  for (int i = 0; items && i < n; ++i) t += rr_align_up(rr_mlp_weight_grad_workspace_bytes(items[i].M, items[i].O, items[i].I), 256);
+  return t;
+}
+extern "C" int rr_mlp_weight_grad_batch(const rr_dw_item* items, int32_t n, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!items || n <= 0 || !workspace) return fail(RR_EINVAL, "rr_mlp_weight_grad_batch: bad argument");
+  if (n > RR_DW_MAXB) return fail(RR_EUNSUPPORTED, "rr_mlp_weight_grad_batch: at most 12 products per call");
+  if (workspace_bytes < rr_mlp_weight_grad_batch_workspace_bytes(items, n)) return fail(RR_EINVAL, "rr_mlp_weight_grad_batch: workspace too small");
+  RRDwBatch all, grp[3];
+  memset(&all, 0, sizeof(all));
+  memset(grp, 0, sizeof(grp));
+  dim3 ggrid[3] = {dim3(0, 0, 0), dim3(0, 0, 0), dim3(0, 0, 0)};
+  unsigned red_blocks = 0;
+  char* w = (char*)workspace;
+  for (int i = 0; i < n; ++i) {
+    const rr_dw_item& it = items[i];
+    if (!it.delta || !it.act || !it.grad || it.M <= 0 || it.O <= 0 || it.I <= 0) return fail(RR_EINVAL, "rr_mlp_weight_grad_batch: bad item");
+    if ((it.mean == nullptr) != (it.std == nullptr) || (it.mean && !it.delta_colsum))
+      return fail(RR_EINVAL, "rr_mlp_weight_grad_batch: mean, std and delta_colsum must be given together");
+    const DwPlan p = dw_plan(it.M, it.O, it.I);
+    RRDwArgs A;
+    memset(&A, 0, sizeof(A));
+    A.rows_per_slice = p.rows_per_slice; A.nslice = p.nslice;
+    A.a = it.delta; A.b = it.act; A.rows = it.act_rows; A.mean = it.mean; A.std_ = it.std; A.bsum = it.delta_colsum; A.M = it.M; A.O = it.O; A.I = it.I;
+    A.part = (float*)w; A.out = it.grad;
+    w += rr_align_up(rr_mlp_weight_grad_workspace_bytes(it.M, it.O, it.I), 256);
+    all.it[all.n++] = A;
+    const int g = p.to == 32 ? 0 : (p.to == 64 ? 1 : 2);
+    grp[g].it[grp[g].n++] = A;
+    ggrid[g].x = std::max<unsigned>(ggrid[g].x, ((it.O + p.to - 1) / p.to) * ((it.I + p.ti - 1) / p.ti));
+    ggrid[g].y = std::max<unsigned>(ggrid[g].y, (unsigned)p.nslice);
+    ggrid[g].z = grp[g].n;
+    red_blocks = std::max<unsigned>(red_blocks, (unsigned)(((size_t)it.O * it.I + 15) / 16));
+  }
+  hipStream_t st = (hipStream_t)stream;
+  int rc = RR_OK;
+  if (grp[2].n) rc = dw_launch<2, 2, 2, 2, 16>(grp[2], ggrid[2], st);      // the big tiles first: they are the long ones
+  if (!rc && grp[1].n) rc = dw_launch<2, 2, 1, 1, 32>(grp[1], ggrid[1], st);
+  if (!rc && grp[0].n) rc = dw_launch<1, 4, 1, 1, 64>(grp[0], ggrid[0], st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(rr_mlp_dw_reduce_kernel, dim3(red_blocks, all.n), dim3(256), 0, st, all);
+  HIPCHK(hipGetLastError());
   return RR_OK;
 }
 extern "C" int rr_mlp_weight_grad(const float* delta, const float* act, const int64_t* act_rows, const float* mean, const float* std_,
                                   const float* delta_colsum, int32_t M, int32_t O, int32_t I, float* grad, void* workspace, size_t workspace_bytes,
                                   void* stream) {
   if (!delta || !act || !grad || !workspace || M <= 0 || O <= 0 || I <= 0) return fail(RR_EINVAL, "rr_mlp_weight_grad: bad argument");
-  if ((mean == nullptr) != (std_ == nullptr) || (mean && !delta_colsum))
-    return fail(RR_EINVAL, "rr_mlp_weight_grad: mean, std and delta_colsum must be given together");
   if (workspace_bytes < rr_mlp_weight_grad_workspace_bytes(M, O, I)) return fail(RR_EINVAL, "rr_mlp_weight_grad: workspace too small (rr_mlp_weight_grad_workspace_bytes)");
-  const DwPlan p = dw_plan(M, O, I);
-  RRDwArgs A;
-  memset(&A, 0, sizeof(A));
-  A.rows_per_slice = p.rows_per_slice; A.nslice = p.nslice;
-  A.a = delta; A.b = act; A.rows = act_rows; A.mean = mean; A.std_ = std_; A.bsum = delta_colsum; A.M = M; A.O = O; A.I = I;
-  A.part = (float*)workspace; A.out = grad;
-  const dim3 grid(((O + p.to - 1) / p.to) * ((I + p.ti - 1) / p.ti), A.nslice);
-  hipStream_t st = (hipStream_t)stream;
-  int rc;
-  if (p.to == 32) rc = dw_launch<1, 4, 1, 1, 64>(A, grid, st);
-  else if (p.to == 64) rc = dw_launch<2, 2, 1, 1, 32>(A, grid, st);
-  else rc = dw_launch<2, 2, 2, 2, 16>(A, grid, st);
-  if (rc) return rc;
-  hipLaunchKernelGGL(rr_mlp_dw_reduce_kernel, dim3((unsigned)(((size_t)O * I + 15) / 16)), dim3(256), 0, st, A);
-  HIPCHK(hipGetLastError());
-  return RR_OK;
+  rr_dw_item it;
+  memset(&it, 0, sizeof(it));
+  it.delta = delta; it.act = act; it.act_rows = act_rows; it.mean = mean; it.std = std_; it.delta_colsum = delta_colsum; it.M = M; it.O = O; it.I = I;
+  it.grad = grad;
+  return rr_mlp_weight_grad_batch(&it, 1, workspace, rr_align_up(workspace_bytes, 256), stream);
 }
 
 // ------------------------------------------------------------------------------------------ training wrappers, fused

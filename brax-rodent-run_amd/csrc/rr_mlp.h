@@ -467,9 +467,18 @@ struct RRDwArgs {
   float* out;                                // [O][I]
 };
 
+// several products in one launch: item blockIdx.z (workgroups past an item's own grid leave at once)
+#define RR_DW_MAXB 12
+struct RRDwBatch { RRDwArgs it[RR_DW_MAXB]; int n; };
+
 template <int GO, int GI, int WO, int WI, int KC>
-__global__ __launch_bounds__(256, 2) void rr_mlp_dw_kernel(const RRDwArgs A) {
+__global__ __launch_bounds__(256, 2) void rr_mlp_dw_kernel(const RRDwBatch B) {
   static_assert(GO * GI == 4, "four wavefronts");
+  const RRDwArgs& A = B.it[blockIdx.z];
+  {
+    constexpr int TO_ = GO * WO * 32, TI_ = GI * WI * 32;
+    if ((int)blockIdx.y >= A.nslice || (int)blockIdx.x >= ((A.O + TO_ - 1) / TO_) * ((A.I + TI_ - 1) / TI_)) return;
+  }
   constexpr int TO = GO * WO * 32, TI = GI * WI * 32;
   constexpr int SA = TO + (TO % 64 == 0 ? 32 : 0), SB = TI + (TI % 64 == 0 ? 32 : 0);
   constexpr int PA = KC * TO / 256, PB = KC * TI / 256;
@@ -585,9 +594,11 @@ __global__ __launch_bounds__(256, 2) void rr_mlp_dw_kernel(const RRDwArgs A) {
 }
 // out[e] = sum_s part[s][e] (then the normaliser, see RRDwArgs): a block owns 16 consecutive outputs, 16 groups of threads each
 // add every 16th slice, the 16 group sums go through LDS in a fixed order
-__global__ __launch_bounds__(256) void rr_mlp_dw_reduce_kernel(const RRDwArgs A) {
+__global__ __launch_bounds__(256) void rr_mlp_dw_reduce_kernel(const RRDwBatch B) {
   __shared__ float sh[256];
+  const RRDwArgs& A = B.it[blockIdx.y];
   const size_t n = (size_t)A.O * A.I;
+  if ((size_t)blockIdx.x * 16 >= n) return;          // uniform: past this item's outputs
   const int c = threadIdx.x & 15, sg = threadIdx.x >> 4;
   const size_t e = (size_t)blockIdx.x * 16 + c;
   float t = 0.0f;

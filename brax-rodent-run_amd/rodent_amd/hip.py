@@ -42,6 +42,11 @@ class RREnvIO(C.Structure):
                 ("terminate_when_unhealthy", C.c_int32)]
 
 
+class RRDwItem(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("delta", "act", "act_rows", "mean", "std", "delta_colsum")] + \
+        [("M", C.c_int32), ("O", C.c_int32), ("I", C.c_int32), ("grad", C.c_void_p)]
+
+
 class RRPpoCfg(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("entropy_cost", "discounting", "reward_scaling", "gae_lambda", "clipping_epsilon", "min_std")] + \
         [("normalize_advantage", C.c_int32)]
@@ -49,7 +54,7 @@ class RRPpoCfg(C.Structure):
 
 EXPORTS = ["rr_model_load", "rr_model_dims", "rr_model_set_solver", "rr_model_set_solver_type", "rr_model_destroy", "rr_model_table", "rr_kernarg_layout", "rr_batch_create",
            "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset", "rr_pipeline_step_to", "rr_env_step_to",
-           "rr_compute_gae", "rr_mlp_forward", "rr_ppo_loss_workspace_bytes", "rr_ppo_loss", "rr_policy_act_workspace_bytes", "rr_policy_act", "rr_policy_sample", "rr_policy_backward_workspace_bytes", "rr_policy_backward", "rr_mlp_silu_backward_workspace_bytes", "rr_mlp_silu_backward", "rr_mlp_value_backward_workspace_bytes", "rr_mlp_value_backward", "rr_mlp_weight_grad_workspace_bytes", "rr_mlp_weight_grad", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_schedule", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
+           "rr_compute_gae", "rr_mlp_forward", "rr_ppo_loss_workspace_bytes", "rr_ppo_loss", "rr_policy_act_workspace_bytes", "rr_policy_act", "rr_policy_sample", "rr_policy_backward_workspace_bytes", "rr_policy_backward", "rr_mlp_silu_backward_workspace_bytes", "rr_mlp_silu_backward", "rr_mlp_value_backward_workspace_bytes", "rr_mlp_value_backward", "rr_mlp_weight_grad_workspace_bytes", "rr_mlp_weight_grad", "rr_mlp_weight_grad_batch_workspace_bytes", "rr_mlp_weight_grad_batch", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_schedule", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
 
 _lib = None
 
@@ -108,6 +113,9 @@ def lib():
         L.rr_mlp_weight_grad_workspace_bytes.argtypes = [C.c_int32] * 3
         L.rr_mlp_weight_grad_workspace_bytes.restype = C.c_size_t
         L.rr_mlp_weight_grad.argtypes = [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.rr_mlp_weight_grad_batch_workspace_bytes.argtypes = [C.POINTER(RRDwItem), C.c_int32]
+        L.rr_mlp_weight_grad_batch_workspace_bytes.restype = C.c_size_t
+        L.rr_mlp_weight_grad_batch.argtypes = [C.POINTER(RRDwItem), C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]
         L.rr_wrap_episode_autoreset.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32)] + \
             [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_void_p]
         L.rr_batch_set_profile.argtypes = [C.c_void_p, C.c_void_p]
@@ -545,3 +553,36 @@ def policy_act(obs, mean, std, policy, noise, min_std: float, want_logits: bool 
                                _ptr(std, numel=K) if std is not None else None, C.byref(pn), p(noise), min_std, action.data_ptr(), p(raw), p(lp),
                                p(logits), ws.data_ptr(), ws.numel() * 4, C.c_void_p(stream)))
     return action, raw, lp, logits
+
+
+_dwb_ws = {}
+
+
+def mlp_weight_grad_batch(items):
+    """Several weight gradients in one call (C ABI `rr_mlp_weight_grad_batch`, at most 12): `items` = dicts with the arguments of
+    `mlp_weight_grad` (delta, act, out, and optionally rows, mean, std, delta_colsum).  Products of one tile shape share a launch,
+    one reduction launch sums all partial tiles."""
+    n = len(items)
+    arr = (RRDwItem * n)()
+    dev = items[0]["delta"].device
+    shape_key = []
+    for i, it in enumerate(items):
+        delta, act, out = it["delta"], it["act"], it["out"]
+        M, O = delta.shape
+        I = act.shape[1]
+        _ptr(delta); _ptr(act); _ptr(out, numel=O * I)
+        rows, mean, std, cs = it.get("rows"), it.get("mean"), it.get("std"), it.get("delta_colsum")
+        if rows is not None:
+            _ptr(rows, torch.int64, M)
+        elif act.shape[0] < M:
+            raise ValueError("rr_mlp_weight_grad_batch: fewer activation rows than delta rows")
+        p = lambda t: t.data_ptr() if t is not None else None
+        arr[i] = RRDwItem(delta.data_ptr(), act.data_ptr(), p(rows), _ptr(mean, numel=I) if mean is not None else None,
+                          _ptr(std, numel=I) if std is not None else None, _ptr(cs, numel=O) if mean is not None else None, M, O, I, out.data_ptr())
+        shape_key.append((M, O, I))
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    key = (dev, tuple(shape_key), stream)
+    if key not in _dwb_ws:
+        _dwb_ws[key] = torch.empty((lib().rr_mlp_weight_grad_batch_workspace_bytes(arr, n) + 3) // 4, device=dev)
+    ws = _dwb_ws[key]
+    _check(lib().rr_mlp_weight_grad_batch(arr, n, ws.data_ptr(), ws.numel() * 4, C.c_void_p(stream)))

@@ -32,33 +32,33 @@ class FusedUpdate:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
 
-    def _policy_backward_into_grads(self, pre, g, obs, rows, mean, std):
+    def _policy_backward(self, pre, g, obs, rows, mean, std):
         """Policy network: the delta chain of the 32-wide stack is one launch (`rr_policy_backward`: delta_j, h_j = silu(z_j) over the
-        forward's dump, bias gradients); the weight gradients are split-row products of its outputs.  g [n, P] covers the first n
-        rows of the minibatch (the bootstrap rows behind them carry no policy gradient)."""
+        forward's dump, bias gradients).  g [n, P] covers the first n rows of the minibatch (the bootstrap rows behind them carry no
+        policy gradient).  Returns the weight-gradient products to be taken (`rr_mlp_weight_grad_batch` items)."""
         layers = self.policy_net.layers
         nh = len(layers) - 1
         n = g.shape[0]
         delta, h = hip.policy_backward(g, layers[nh].weight, [None] + [layers[j].weight for j in range(1, nh)], pre,
                                        [layers[j].bias.grad for j in range(nh)], self.bufs)
         torch.sum(g, 0, out=layers[nh].bias.grad)
-        hip.mlp_weight_grad(g, h[nh - 1, :n], layers[nh].weight.grad)
-        for j in range(nh - 1, 0, -1):
-            hip.mlp_weight_grad(delta[j], h[j - 1, :n], layers[j].weight.grad)
-        hip.mlp_weight_grad(delta[0], obs, layers[0].weight.grad, rows=rows, mean=mean, std=std, delta_colsum=layers[0].bias.grad)
+        items = [dict(delta=g, act=h[nh - 1, :n], out=layers[nh].weight.grad)]
+        items += [dict(delta=delta[j], act=h[j - 1, :n], out=layers[j].weight.grad) for j in range(nh - 1, 0, -1)]
+        items.append(dict(delta=delta[0], act=obs, out=layers[0].weight.grad, rows=rows, mean=mean, std=std, delta_colsum=layers[0].bias.grad))
+        return items
 
-    def _value_backward_into_grads(self, pre, g, obs, rows, mean, std):
+    def _value_backward(self, pre, g, obs, rows, mean, std):
         """Value network: the delta chain (dX products, silu', h = silu(z), bias gradients) is ONE matrix-core launch
-        (`rr_mlp_value_backward`); the weight gradients are split-row matrix-core products of its outputs."""
+        (`rr_mlp_value_backward`); returns the weight-gradient products of its outputs."""
         layers = self.value_net.layers
         nh = len(layers) - 1
         wt = [None] + [layers[j].weight.t().contiguous() for j in range(1, nh)]
         delta, h = hip.mlp_value_backward(g, layers[nh].weight, wt, pre, [layers[j].bias.grad for j in range(nh)], self.bufs)
         torch.sum(g, 0, keepdim=True, out=layers[nh].bias.grad)
-        hip.mlp_weight_grad(g.unsqueeze(1), h[nh - 1], layers[nh].weight.grad)
-        for j in range(nh - 1, 0, -1):
-            hip.mlp_weight_grad(delta[j], h[j - 1], layers[j].weight.grad)
-        hip.mlp_weight_grad(delta[0], obs, layers[0].weight.grad, rows=rows, mean=mean, std=std, delta_colsum=layers[0].bias.grad)
+        items = [dict(delta=g.unsqueeze(1), act=h[nh - 1], out=layers[nh].weight.grad)]
+        items += [dict(delta=delta[j], act=h[j - 1], out=layers[j].weight.grad) for j in range(nh - 1, 0, -1)]
+        items.append(dict(delta=delta[0], act=obs, out=layers[0].weight.grad, rows=rows, mean=mean, std=std, delta_colsum=layers[0].bias.grad))
+        return items
 
     @torch.no_grad()
     def __call__(self, data, idx, mean, std, generator=None):
@@ -75,6 +75,6 @@ class FusedUpdate:
         noise = torch.randn(T * B, A, device=obs.device, dtype=obs.dtype, generator=generator)     # the draw of dist.entropy
         g_pol, g_val, metrics = hip.ppo_loss(pol, val, data, idx, noise, T, out=self.bufs, **self.cfg)
         n = T * B                                                                           # the bootstrap rows carry no policy gradient
-        self._policy_backward_into_grads(ppre, g_pol[:n], obs, rows[:n], mean, std)
-        self._value_backward_into_grads(vpre, g_val, obs, rows, mean, std)
+        items = self._policy_backward(ppre, g_pol[:n], obs, rows[:n], mean, std) + self._value_backward(vpre, g_val, obs, rows, mean, std)
+        hip.mlp_weight_grad_batch(items)            # all eleven dW = delta' h: one launch per tile shape + one reduction launch
         return {"total_loss": metrics[0], "policy_loss": metrics[1], "v_loss": metrics[2], "entropy_loss": metrics[3]}

@@ -295,8 +295,9 @@ def test_policy_act_two_launches(M, K, use_rows):
     eps = torch.randn(M, A, device=DEV)
     x = obs[rows] if use_rows else obs
     net64 = copy.deepcopy(net).double()
-    lg64 = net64((x.double() - mean.double()) / std.double())
-    lg32 = net((x - mean) / std).double()
+    with torch.no_grad():
+        lg64 = net64((x.double() - mean.double()) / std.double())
+        lg32 = net((x - mean) / std).double()
     loc, scale = dist._params(lg64)
     raw64 = loc + scale * eps.double()
     lp64 = dist.log_prob(lg64, raw64)
@@ -313,3 +314,29 @@ def test_policy_act_two_launches(M, K, use_rows):
     act_d, raw_d, lp_d, _ = hip.policy_act(obs, mean, std, fused_mlp.net_params(net), None, dist.min_std, rows=rows)
     assert raw_d is None and lp_d is None
     assert (act_d.double() - torch.tanh(loc)).abs().max() <= tol + 1e-5
+
+
+def test_weight_grad_batch_equals_single_calls():
+    """rr_mlp_weight_grad_batch (products of one tile shape share a launch, one reduction) gives bit for bit what the per-layer
+    calls give."""
+    from rodent_amd import hip
+    g = torch.Generator(device=DEV).manual_seed(2)
+    M, K = 4096, 1263
+    obs = torch.randn(M + 9, K, device=DEV, generator=g)
+    rows = torch.randperm(M + 9, device=DEV, generator=g)[:M]
+    mean, std = torch.randn(K, device=DEV, generator=g) * 0.2, torch.rand(K, device=DEV, generator=g) + 0.5
+    mk = lambda o: torch.randn(M, o, device=DEV, generator=g)
+    specs = [(mk(60), mk(32), {}), (mk(32), mk(32), {}), (mk(32), mk(32), {}), (mk(32), obs, dict(rows=rows, mean=mean, std=std)),
+             (mk(1), mk(256), {}), (mk(256), mk(256), {}), (mk(256), mk(256), {}), (mk(256), obs, dict(rows=rows, mean=mean, std=std))]
+    single, items = [], []
+    for d, a, kw in specs:
+        if kw:
+            kw = dict(kw, delta_colsum=d.sum(0))
+        out1, out2 = torch.empty(d.shape[1], a.shape[1], device=DEV), torch.empty(d.shape[1], a.shape[1], device=DEV)
+        hip.mlp_weight_grad(d, a, out1, **kw)
+        single.append(out1)
+        items.append(dict(delta=d, act=a, out=out2, **kw))
+    hip.mlp_weight_grad_batch(items)
+    torch.cuda.synchronize()
+    for s1, it in zip(single, items):
+        assert torch.isfinite(s1).all() and torch.equal(s1, it["out"])
