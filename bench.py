@@ -120,6 +120,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--substreams", type=int, default=2, help="config 2: the envs of a GPU are stepped as this many sub-batches on separate "
                     "HIP streams (one sub-batch's slowest envs overlap the others' bulk); 1 = one launch per step")
+    ap.add_argument("--unroll", type=int, default=5, help="config 2: env steps per launch (rr_env_unroll: the wrapped step scanned inside the kernel, "
+                    "actions drawn for that many steps at a time); 1 = one launch per step (HIP-graph replay unless --no-graph)")
     ap.add_argument("--no-graph", action="store_true", help="config 2: issue every step from the host instead of replaying a HIP graph of it")
     ap.add_argument("--solver", default="cg", choices=("cg", "newton"), help="config 2 only; the headline configuration is cg 8/8")
     ap.add_argument("--iterations", type=int, default=8)
@@ -253,6 +255,26 @@ def main():
             eager_steps(args.warmup)
             torch.cuda.synchronize(dev)
             R_ = 1
+            UT_ = max(r for r in range(1, max(args.unroll, 1) + 1) if args.steps % r == 0)      # env steps per launch
+            if UT_ > 1:
+                # multi-step launches: the rollout's scan over the wrapped step runs INSIDE the kernel (envs never wait for each other between
+                # steps, state on chip, wrappers in place; bit-identical to the per-step calls: tests/test_gpu_env.py)
+                workload = (f"{model}.xml random-action rollout, Rodent.step through Episode(150)+AutoReset wrappers, "
+                            f"{args.solver.upper()} {args.iterations}/{args.ls_iterations}, n_frames 10; {S_} sub-batches of {n_sub} envs on {S_} streams, "
+                            f"{UT_} env steps per launch (rr_env_unroll)")
+                args.no_graph = True
+
+                def unroll_steps(k):
+                    for _ in range(k // UT_):
+                        for sub in subs:
+                            with torch.cuda.stream(sub["stream"]):
+                                a_ = torch.empty(UT_, n_sub, nu, device=dev).uniform_(-1.0, 1.0, generator=sub["gen"])
+                                sub["state"] = sub["wenv"].unroll(sub["state"], a_)
+                unroll_steps(2 * UT_)
+                torch.cuda.synchronize(dev)
+                for sub in subs:
+                    sub["env"]._batch.set_timing(True)        # live: HIP events around every launch of the timed region
+                eager_steps = unroll_steps
             if not args.no_graph:
                 R_ = max(r for r in range(1, 11) if args.steps % r == 0)            # steps per replay
                 try:
@@ -281,16 +303,17 @@ def main():
             assert all(torch.isfinite(sub["state"].obs).all() for sub in subs), "non-finite state in the rollout"
             # kernel durations by HIP events on each sub-batch's stream: a host-issued pass over the same states (events cannot be
             # read back from inside a replayed graph); rocprofv3's kernel trace of this command shows the replayed launches themselves
-            for sub in subs:
-                sub["env"]._batch.set_timing(True)
-            eager_steps(args.steps if args.no_graph else min(args.steps, 100))
+            if UT_ == 1:
+                for sub in subs:
+                    sub["env"]._batch.set_timing(True)
+                eager_steps(args.steps if args.no_graph else min(args.steps, 100))
             torch.cuda.synchronize(dev)
             kt = [sub["env"]._batch.kernel_time() for sub in subs]
             kern_ms, launches = sum(k[0] for k in kt), sum(k[1] for k in kt)
             batch = subs[0]["env"]._batch
             total_env_steps = N * world * args.steps
             elapsed = float(np.median(repeats_ms)) * args.steps * 1e-3
-            extra = {"substreams": S_, "steps_per_graph_replay": None if args.no_graph else R_}
+            extra = {"substreams": S_, "steps_per_graph_replay": None if args.no_graph else R_, "env_steps_per_launch": UT_}
         else:
             # ---- config 5: rodent_pair.xml (two replicated rodents, nv 146, 114 contacts), physics only (pipeline_step)
             from rodent_amd import assets, hip, mjcf
@@ -341,11 +364,12 @@ def main():
         avg_kernel_s = (kern_ms / max(launches, 1)) * 1e-3
         # config 2: `substreams` launches of N / substreams envs are in flight together, each lasting avg_kernel_s
         concurrent = extra.get("substreams", 1)
-        achieved = bytes_per_env_step * (N // concurrent) * concurrent / avg_kernel_s / 1e9
+        per_launch = extra.get("env_steps_per_launch", 1)          # env steps of every env inside one launch
+        achieved = bytes_per_env_step * (N // concurrent) * per_launch * concurrent / avg_kernel_s / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic() if args.config == 2 else None,
                 "kernel": "rr_step_kernel", "avg_kernel_ms": avg_kernel_s * 1e3, "launches": launches,
-                "envs_per_launch": N // concurrent, "concurrent_launches": concurrent,
+                "envs_per_launch": N // concurrent, "concurrent_launches": concurrent, "env_steps_per_launch": per_launch,
                 "algorithmic_bytes_per_env_step": bytes_per_env_step,
                 "limiter": "VALU issue + dependent LDS/L2 latency, not HBM (SURVEY.md 8(d)); see valu_busy_frac"}
         if args.config == 2:

@@ -196,7 +196,7 @@ struct rr_batch {
   std::vector<void*> dev_allocs;
   bool timing = false;
   std::vector<hipEvent_t> ev0, ev1;     // ring of event pairs: launches are timed without a host sync per launch
-  int npending = 0;
+  int npending = 0, ring_head = 0;      // pending pairs are ring_head .. ring_head + npending - 1 (mod the ring size)
   double total_ms = 0;
   int64_t launches = 0;
   unsigned long long* prof = nullptr;   // diagnostic phase-cycle buffer (rr_batch_set_profile)
@@ -257,6 +257,11 @@ static kern_t pick_kernel(const rr_model* m, bool prof = false, bool dbg = false
   return nullptr;
 }
 
+static kern_t pick_unroll_kernel(const rr_model* m) {
+  if (m->solver == 2 || !(m->NBS == 2 && m->NVS == 2 && m->NCS == 1)) return nullptr;
+  return RRDimsRodent::matches(m->kd) ? rr_step_kernel<2, 2, 1, false, false, RRDimsRodent, false, true> : rr_step_kernel<2, 2, 1, false, false, RRDims, false, true>;
+}
+
 extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t device, void* stream, rr_batch** out) {
   if (!m || !out || num_envs <= 0) return fail(RR_EINVAL, "rr_batch_create: bad argument");
   if (!pick_kernel(m)) return fail(RR_EUNSUPPORTED, "rr_batch_create: no kernel instance for this model's slot counts");
@@ -307,20 +312,30 @@ extern "C" void rr_batch_destroy(rr_batch* b) {
 }
 
 #define RR_TIMING_RING 256
-static int collect_timing(rr_batch* b) {
-  if (b->npending > 0) HIPCHK(hipEventSynchronize(b->ev1[b->npending - 1]));    // same stream: the earlier ones are done too
-  for (int i = 0; i < b->npending; ++i) {
+// Fold finished event pairs into the totals.  `all`: wait for every pending launch (rr_batch_kernel_time).  Otherwise (the ring is
+// full at a launch) only pairs that HAVE finished are taken, oldest first, without blocking -- a blocking drain stalled the host
+// for the length of the launch in flight, long enough with multi-step launches for a second stream to run dry -- and if none has,
+// the oldest one is waited for.
+static int collect_timing(rr_batch* b, bool all = true) {
+  bool first = true;
+  while (b->npending > 0) {
+    const int i = b->ring_head;
+    if (all || (first && hipEventQuery(b->ev1[i]) != hipSuccess)) HIPCHK(hipEventSynchronize(b->ev1[i]));
+    else if (hipEventQuery(b->ev1[i]) != hipSuccess) break;
+    first = false;
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, b->ev0[i], b->ev1[i]));
     b->total_ms += ms;
     b->launches += 1;
+    b->ring_head = (i + 1) % RR_TIMING_RING;
+    b->npending -= 1;
   }
-  b->npending = 0;
+  (void)hipGetLastError();      // hipEventQuery reports "not ready" through the sticky last-error slot
   return RR_OK;
 }
 
 static int launch(rr_batch* b, const rr_state* st, const float* ctrl, int n_frames, const rr_env_io* env, const rr_outputs* out, int mode,
-                  const rr_state* st_in = nullptr, const int32_t* cur_frame_in = nullptr) {
+                  const rr_state* st_in = nullptr, const int32_t* cur_frame_in = nullptr, const rr_unroll_io* un = nullptr, int unroll_T = 0) {
   if (!b || !st || !st->qpos || !st->qvel || !st->act || !st->qacc_warmstart) return fail(RR_EINVAL, "launch: null state pointer");
   if (st_in && (!st_in->qpos || !st_in->qvel || !st_in->act || !st_in->qacc_warmstart)) return fail(RR_EINVAL, "launch: null input state pointer");
   if ((mode & 1) && (!ctrl || n_frames <= 0)) return fail(RR_EINVAL, "launch: step needs ctrl and n_frames > 0");
@@ -346,19 +361,27 @@ static int launch(rr_batch* b, const rr_state* st, const float* ctrl, int n_fram
   io.mode = mode;
   HIPCHK(hipSetDevice(b->device));
   kern_t kern = pick_kernel(b->m, b->prof != nullptr, io.dbg != nullptr || io.o_cdist || io.o_cpos || io.o_cframe);
+  if (un) {      // multi-step rollout: the UNROLL instance, no diagnostics
+    if (b->prof || io.dbg || io.o_cdist || io.o_cpos || io.o_cframe || out) return fail(RR_EUNSUPPORTED, "rr_env_unroll: no diagnostic outputs in a multi-step rollout");
+    kern = pick_unroll_kernel(b->m);
+    if (!kern) return fail(RR_EUNSUPPORTED, "rr_env_unroll: no multi-step kernel instance for this model / solver");
+    io.first_qpos = un->first.qpos; io.first_qvel = un->first.qvel; io.first_act = un->first.act; io.first_warm = un->first.qacc_warmstart;
+    io.first_obs = un->first_obs; io.prev_done = un->prev_done; io.steps_in = un->steps_in; io.steps_out = un->steps_out;
+    io.trunc_out = un->truncation_out; io.episode_length = un->episode_length; io.unroll_T = unroll_T;
+  }
   if (!kern) return fail(RR_EUNSUPPORTED, "launch: no diagnostic kernel instance for this model");
   io.prof = b->prof;
   io.env_map = b->env_map; io.cost = b->cost;
   RRDims kd = b->kd;
   kd.iterations = b->m->kd.iterations; kd.ls_iterations = b->m->kd.ls_iterations;
   if (b->timing) {
-    if (b->npending == RR_TIMING_RING) { int rc = collect_timing(b); if (rc) return rc; }
-    HIPCHK(hipEventRecord(b->ev0[b->npending], b->stream));
+    if (b->npending == RR_TIMING_RING) { int rc = collect_timing(b, false); if (rc) return rc; }
+    HIPCHK(hipEventRecord(b->ev0[(b->ring_head + b->npending) % RR_TIMING_RING], b->stream));
   }
   hipLaunchKernelGGL(kern, dim3(b->N), dim3(RR_LANES), (size_t)b->m->dims.lds_bytes, b->stream, kd, b->T, io, b->N, n_frames);
   HIPCHK(hipGetLastError());
   if (b->timing) {
-    HIPCHK(hipEventRecord(b->ev1[b->npending], b->stream));
+    HIPCHK(hipEventRecord(b->ev1[(b->ring_head + b->npending) % RR_TIMING_RING], b->stream));
     b->npending += 1;
   }
   return RR_OK;
@@ -373,6 +396,14 @@ extern "C" int rr_env_step_to(rr_batch* b, const rr_state* in, const rr_state* o
   if (!env) return fail(RR_EINVAL, "rr_env_step_to: env io required");
   if (!in || !cur_frame_in) return fail(RR_EINVAL, "rr_env_step_to: null input state");
   return launch(b, outst, action, n_frames, env, out, 1, in, cur_frame_in);
+}
+extern "C" int rr_env_unroll(rr_batch* b, const rr_state* in, const rr_state* outst, const float* actions, int32_t num_steps, int32_t n_frames,
+                             const rr_env_io* env, const int32_t* cur_frame_in, const rr_unroll_io* wrap) {
+  if (!env || !in || !cur_frame_in || !wrap || !actions || num_steps <= 0) return fail(RR_EINVAL, "rr_env_unroll: bad argument");
+  if (!wrap->first.qpos || !wrap->first.qvel || !wrap->first.act || !wrap->first.qacc_warmstart || !wrap->first_obs || !wrap->prev_done ||
+      !wrap->steps_in || !wrap->steps_out || !wrap->truncation_out)
+    return fail(RR_EINVAL, "rr_env_unroll: null wrapper pointer");
+  return launch(b, outst, actions, n_frames, env, nullptr, 1, in, cur_frame_in, wrap, num_steps);
 }
 extern "C" int rr_pipeline_init(rr_batch* b, const rr_state* st, const rr_outputs* out) { return launch(b, st, nullptr, 1, nullptr, out, 0); }
 extern "C" int rr_pipeline_step(rr_batch* b, const rr_state* st, const float* ctrl, int32_t n_frames, const rr_outputs* out) {
@@ -804,7 +835,7 @@ extern "C" int rr_batch_set_timing(rr_batch* b, int32_t enable) {
     }
   }
   b->timing = enable != 0;
-  b->total_ms = 0; b->launches = 0; b->npending = 0;
+  b->total_ms = 0; b->launches = 0; b->npending = 0; b->ring_head = 0;
   return RR_OK;
 }
 extern "C" int rr_batch_kernel_time(rr_batch* b, double* total_ms, int64_t* launches) {

@@ -133,7 +133,15 @@ struct RRIO {
   unsigned long long* prof;  // diagnostic build only: [N][RR_NPH] cycle sums per phase
   const int* env_map;        // nullable [N]: workgroup -> environment (SIMD pairing of heavy with light environments, rr_batch_set_schedule)
   unsigned* cost;            // nullable [N]: work estimate of this launch per environment (line-search point evaluations x row blocks)
+  // multi-step rollout (UNROLL instances, rr_env_unroll): unroll_T env steps in one launch, the Episode + AutoReset training wrappers
+  // applied in place between them; ctrl is then [unroll_T][N][nu]
+  const float *first_qpos, *first_qvel, *first_act, *first_warm, *first_obs;   // the stored first state (restored where done)
+  const float *prev_done, *steps_in;                                           // wrapper state before the launch [N]
+  float *steps_out, *trunc_out;                                                // ... and after it
+  float episode_length;
+  int unroll_T;
   int mode;  // 0 = forward only (pipeline_init), 1 = step; bit 1 (2) = env epilogue as reset (obs only)
+  int pad_;
 };
 
 // ------------------------------------------------------------------------------------------ small math
@@ -1801,7 +1809,11 @@ static __device__ __forceinline__ RRIO load_io() {
 #endif
 }
 
-template <int NBS, int NVS, int NCS, bool PROF, bool DBG, class DT, bool NEWTON = false>
+// UNROLL: io.unroll_T env steps per launch.  The environments of a launch never wait for each other between steps (a synchronised
+// step lasts as long as its slowest environment; over ten unsynchronised steps the slowest SUM is 6.5 % below ten slowest steps,
+// tools/tail_probe.py), the state stays in LDS from step to step, and the Episode + AutoReset wrappers
+// (brax.envs.wrappers.training; rr_wrap_episode_autoreset is their one-launch form) are applied in place.
+template <int NBS, int NVS, int NCS, bool PROF, bool DBG, class DT, bool NEWTON = false, bool UNROLL = false>
 __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(const RRDims Dk, const RRTables T, const RRIO io_kernarg, const int num_envs,
                                                            const int n_frames) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1828,17 +1840,31 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
   // the debug dump (parity tests) is a separate instance: its paths keep dozens of values alive across the solver
   float* dbg = (DBG && io.dbg) ? io.dbg + (size_t)env * D.dbg_floats : nullptr;     // DBG instance without a dump buffer: contact outputs only
 
-  // ---- load state
-  for (int i = lane; i < D.nq; i += RR_LANES) w.s_qpos[i] = io.qpos_in[(size_t)env * D.nq + i];
-  for (int i = lane; i < D.nv; i += RR_LANES) w.s_qvel[i] = io.qvel_in[(size_t)env * D.nv + i];
-  for (int i = lane; i < D.nu; i += RR_LANES) {
-    w.s_act[i] = io.act_in[(size_t)env * D.nu + i];
-    w.s_ctrl[i] = io.ctrl ? io.ctrl[(size_t)env * D.nu + i] : 0.0f;
+  // wrapper state of a multi-step rollout, wave-uniform
+  const int nsteps = UNROLL ? io.unroll_T : 1;
+  float u_steps = 0.0f, u_prev_done = 0.0f;
+  int u_frame = 0;
+  if (UNROLL) {
+    u_steps = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(io.steps_in[env])));
+    u_prev_done = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(io.prev_done[env])));
+    u_frame = __builtin_amdgcn_readfirstlane(io.cur_frame_in[env]);
   }
+  int niter = 0;
+  float xq1[4] = {1, 0, 0, 0};   // xquat of body 1 at the last forward pass (obs: xmat[1])
+ for (int ut = 0; ut < nsteps; ++ut) {
+  if (UNROLL) { lane = opaque(lane); w.lane = lane; asm volatile("" : "+s"(env)); io = load_io(); }
+  const size_t ctrl_at = UNROLL ? ((size_t)ut * num_envs + env) * D.nu : (size_t)env * D.nu;
+  // ---- load state (a multi-step rollout keeps it in LDS after its first step)
+  if (!UNROLL || ut == 0) {
+    for (int i = lane; i < D.nq; i += RR_LANES) w.s_qpos[i] = io.qpos_in[(size_t)env * D.nq + i];
+    for (int i = lane; i < D.nv; i += RR_LANES) w.s_qvel[i] = io.qvel_in[(size_t)env * D.nv + i];
+    for (int i = lane; i < D.nu; i += RR_LANES) w.s_act[i] = io.act_in[(size_t)env * D.nu + i];
+  }
+  for (int i = lane; i < D.nu; i += RR_LANES) w.s_ctrl[i] = io.ctrl ? io.ctrl[ctrl_at + i] : 0.0f;
 #pragma unroll
   for (int s = 0; s < NVS; ++s) {
     const int d = lane + RR_LANES * s;
-    if (d < D.nv) w.s_warm[d] = io.warm_in[(size_t)env * D.nv + d];
+    if ((!UNROLL || ut == 0) && d < D.nv) w.s_warm[d] = io.warm_in[(size_t)env * D.nv + d];
     if (d < D.nv) {
       auto di = T.dof_i + RR_DOFI * d;
       w.dofc0[s] = (di[3] & 255) | ((di[2] & 15) << 8) | ((di[9] & 15) << 12) | ((di[0] & 255) << 16) | ((T.body_i[RR_BODYI * di[0]] & 255) << 24);
@@ -1860,8 +1886,6 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
 
   if (PROF) { for (int i = 0; i < RR_NPH; ++i) w.pt[i] = 0; w.pt_last = __builtin_readcyclecounter(); }
   const int frames = (mode & 1) ? n_frames : 1;
-  int niter = 0;
-  float xq1[4] = {1, 0, 0, 0};   // xquat of body 1 at the last forward pass (obs: xmat[1])
   for (int f = 0; f < frames; ++f) {
     // RR_FRAME_LOCAL: everything derived from the lane id / env id (per-lane table addresses, output offsets) is loop-invariant,
     // so the optimiser hoists it out of the substep loop and -- with 256 registers taken -- spills it to scratch at the loop head
@@ -2022,23 +2046,25 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
   io = load_io();
   if (PROF && io.prof && lane == 0) for (int i = 0; i < RR_NPH; ++i) io.prof[(size_t)env * RR_NPH + i] = w.pt[i];
   if (io.cost && lane == 0) io.cost[env] = (unsigned)w.work;
-  // ---- write back state
-  for (int i = lane; i < D.nq; i += RR_LANES) io.qpos[(size_t)env * D.nq + i] = w.s_qpos[i];
-  for (int i = lane; i < D.nv; i += RR_LANES) io.qvel[(size_t)env * D.nv + i] = w.s_qvel[i];
-  for (int i = lane; i < D.nu; i += RR_LANES) io.act[(size_t)env * D.nu + i] = w.s_act[i];
+  // ---- write back state (a multi-step rollout writes it once, after the wrappers of its last step: see below)
+  if (!UNROLL) {
+    for (int i = lane; i < D.nq; i += RR_LANES) io.qpos[(size_t)env * D.nq + i] = w.s_qpos[i];
+    for (int i = lane; i < D.nv; i += RR_LANES) io.qvel[(size_t)env * D.nv + i] = w.s_qvel[i];
+    for (int i = lane; i < D.nu; i += RR_LANES) io.act[(size_t)env * D.nu + i] = w.s_act[i];
 #pragma unroll
-  for (int s = 0; s < NVS; ++s) {
-    const int d = lane + RR_LANES * s;
-    if (d < D.nv) {
-      io.warm[(size_t)env * D.nv + d] = w.s_warm[d];
-      if (io.o_qfrc_actuator) io.o_qfrc_actuator[(size_t)env * D.nv + d] = w.s_qact[d];
+    for (int s = 0; s < NVS; ++s) {
+      const int d = lane + RR_LANES * s;
+      if (d < D.nv) {
+        io.warm[(size_t)env * D.nv + d] = w.s_warm[d];
+        if (io.o_qfrc_actuator) io.o_qfrc_actuator[(size_t)env * D.nv + d] = w.s_qact[d];
+      }
     }
   }
 
   // ---- reference env epilogue [REF Rodent_Env_Brax.py:103-158]
   if (io.obs) {
     const bool is_reset = (mode & 2) != 0;
-    const int old_frame = io.cur_frame_in[env];
+    const int old_frame = UNROLL ? u_frame : io.cur_frame_in[env];
     const int new_frame = is_reset ? old_frame : old_frame + 1;
     float* ob = io.obs + (size_t)env * D.obs_dim;
     int o = 0;
@@ -2065,7 +2091,7 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
     }
     if (!is_reset) {
       float a2 = 0.0f;
-      for (int i = lane; i < D.nu; i += RR_LANES) { const float a = io.ctrl[(size_t)env * D.nu + i]; a2 += a * a; }
+      for (int i = lane; i < D.nu; i += RR_LANES) { const float a = io.ctrl[ctrl_at + i]; a2 += a * a; }
       a2 = wave_sum(a2);
       if (lane == 0) {
         int fi = old_frame < 0 ? 0 : (old_frame > io.track_len - 1 ? io.track_len - 1 : old_frame);
@@ -2082,5 +2108,33 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
         io.cur_frame[env] = new_frame;
       }
     }
+    if (UNROLL) {
+      // EpisodeWrapper + AutoResetWrapper on the step just made (action_repeat 1), as rr_wrap_kernel applies them:
+      // steps' = (prev_done ? 0 : steps) + 1; over = steps' >= episode_length; done <- over ? 1 : done; truncation = over ? 1 - done_env : 0;
+      // where done, the stored first state and first observation come back (info -- cur_frame, steps -- is not restored)
+      const float z = w.s_qpos[2];
+      const float healthy = (z < io.z_min || z > io.z_max) ? 0.0f : 1.0f;
+      const float done_env = io.terminate_when_unhealthy ? 1.0f - healthy : 0.0f;
+      u_steps = (u_prev_done != 0.0f ? 0.0f : u_steps) + 1.0f;
+      const bool over = u_steps >= io.episode_length;
+      const float done2 = over ? 1.0f : done_env, trunc = over ? 1.0f - done_env : 0.0f;
+      u_prev_done = done2;
+      u_frame = new_frame;
+      if (__builtin_amdgcn_readfirstlane(__float_as_int(done2)) != 0) {
+        w.sync();
+        for (int i = lane; i < D.nq; i += RR_LANES) w.s_qpos[i] = io.first_qpos[(size_t)env * D.nq + i];
+        for (int i = lane; i < D.nv; i += RR_LANES) { w.s_qvel[i] = io.first_qvel[(size_t)env * D.nv + i]; w.s_warm[i] = io.first_warm[(size_t)env * D.nv + i]; }
+        for (int i = lane; i < D.nu; i += RR_LANES) w.s_act[i] = io.first_act[(size_t)env * D.nu + i];
+        for (int i = lane; i < D.obs_dim; i += RR_LANES) ob[i] = io.first_obs[(size_t)env * D.obs_dim + i];
+        w.sync();
+      }
+      if (ut == nsteps - 1) {
+        if (lane == 0) { io.done[env] = done2; io.steps_out[env] = u_steps; io.trunc_out[env] = trunc; }
+        for (int i = lane; i < D.nq; i += RR_LANES) io.qpos[(size_t)env * D.nq + i] = w.s_qpos[i];
+        for (int i = lane; i < D.nv; i += RR_LANES) { io.qvel[(size_t)env * D.nv + i] = w.s_qvel[i]; io.warm[(size_t)env * D.nv + i] = w.s_warm[i]; }
+        for (int i = lane; i < D.nu; i += RR_LANES) io.act[(size_t)env * D.nu + i] = w.s_act[i];
+      }
+    }
   }
+ }     // ut
 }

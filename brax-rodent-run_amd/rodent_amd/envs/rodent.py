@@ -99,6 +99,32 @@ class Rodent(PipelineEnv):
         metrics = {"pos_reward": zero, "reward_quadctrl": zero.clone(), "reward_alive": zero.clone()}
         return State(PipelineState(**st, **out), obs, zero.clone(), zero.clone(), metrics, {"cur_frame": cur_frame})
 
+    def unroll_wrapped(self, state: State, actions: torch.Tensor, episode_length: float) -> State:
+        """`actions.shape[0]` steps with `EpisodeWrapper(episode_length)` + `AutoResetWrapper` (action_repeat 1) in ONE launch
+        (`rr_env_unroll`): what `lax.scan` over the wrapped `step` is to the reference.  `state` is a state of the wrapped env
+        (info carries steps, truncation, first_pipeline_state, first_obs); returns the state after the last step, bit for bit what
+        the per-step calls give.  Intermediate observations / rewards are not returned (a random-action rollout needs none)."""
+        if self._pipeline_outputs or self._contact_outputs:
+            raise ValueError("a multi-step rollout returns no pipeline / contact outputs: build the env without them")
+        N, dev, s = self.num_envs, self.device, self.sys
+        ps, info = state.pipeline_state, state.info
+        fps = info["first_pipeline_state"]
+        st_in = dict(qpos=ps.qpos, qvel=ps.qvel, act=ps.act, qacc_warmstart=ps.qacc_warmstart)
+        first = dict(qpos=fps.qpos, qvel=fps.qvel, act=fps.act, qacc_warmstart=fps.qacc_warmstart)
+        st = {k: torch.empty_like(v) for k, v in st_in.items()}
+        cur_frame = torch.empty_like(info["cur_frame"])
+        obs = torch.empty(N, s.obs_dim, device=dev)
+        reward, done, steps, trunc = (torch.empty(N, device=dev) for _ in range(4))
+        metrics = torch.empty(N, 3, device=dev)
+        actions = actions.to(dev, torch.float32).contiguous()
+        self._batch.env_unroll(st_in, st, actions, self._n_frames, self._env_io(cur_frame, obs, reward, done, metrics), info["cur_frame"],
+                               first, info["first_obs"], state.done, info["steps"], steps, trunc, episode_length)
+        ninfo = dict(info)
+        ninfo.update(cur_frame=cur_frame, steps=steps, truncation=trunc)
+        m = dict(state.metrics)
+        m.update(pos_reward=metrics[:, 0], reward_quadctrl=metrics[:, 1], reward_alive=metrics[:, 2])
+        return state.replace(pipeline_state=PipelineState(**st), obs=obs, reward=reward, done=done, metrics=m, info=ninfo)
+
     def step(self, state: State, action: torch.Tensor) -> State:
         """Runs one timestep of the environment's dynamics."""
         N, dev, s = self.num_envs, self.device, self.sys

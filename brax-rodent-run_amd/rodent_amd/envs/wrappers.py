@@ -169,6 +169,13 @@ class FusedEpisodeAutoResetWrapper(Wrapper):
         return nstate
 
 
+    def unroll(self, state, actions):
+        """`actions` [T, N, nu]: T wrapped steps in one launch (`Rodent.unroll_wrapped` / C ABI `rr_env_unroll`); the state after the
+        last step, equal to T calls of `step` bit for bit."""
+        base = self.env.unwrapped if hasattr(self.env, "unwrapped") else self.env
+        return base.unroll_wrapped(state, actions, self.episode_length)
+
+
 def wrap(env, episode_length: int = 1000, action_repeat: int = 1):
     """brax.envs.wrappers.training.wrap: Vmap -> Episode -> AutoReset (one fused wrapper for a HIP env with
     action_repeat 1; RR_FUSED_WRAPPERS=0 selects the composition)."""

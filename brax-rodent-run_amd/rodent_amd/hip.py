@@ -42,6 +42,11 @@ class RREnvIO(C.Structure):
                 ("terminate_when_unhealthy", C.c_int32)]
 
 
+class RRUnrollIO(C.Structure):
+    _fields_ = [("first", RRState), ("first_obs", C.c_void_p), ("prev_done", C.c_void_p), ("steps_in", C.c_void_p), ("steps_out", C.c_void_p),
+                ("truncation_out", C.c_void_p), ("episode_length", C.c_float)]
+
+
 class RRDwItem(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("delta", "act", "act_rows", "mean", "std", "delta_colsum")] + \
         [("M", C.c_int32), ("O", C.c_int32), ("I", C.c_int32), ("grad", C.c_void_p)]
@@ -53,7 +58,7 @@ class RRPpoCfg(C.Structure):
 
 
 EXPORTS = ["rr_model_load", "rr_model_dims", "rr_model_set_solver", "rr_model_set_solver_type", "rr_model_destroy", "rr_model_table", "rr_kernarg_layout", "rr_batch_create",
-           "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset", "rr_pipeline_step_to", "rr_env_step_to",
+           "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset", "rr_pipeline_step_to", "rr_env_step_to", "rr_env_unroll",
            "rr_compute_gae", "rr_mlp_forward", "rr_ppo_loss_workspace_bytes", "rr_ppo_loss", "rr_policy_act_workspace_bytes", "rr_policy_act", "rr_policy_sample", "rr_policy_backward_workspace_bytes", "rr_policy_backward", "rr_mlp_silu_backward_workspace_bytes", "rr_mlp_silu_backward", "rr_mlp_value_backward_workspace_bytes", "rr_mlp_value_backward", "rr_mlp_weight_grad_workspace_bytes", "rr_mlp_weight_grad", "rr_mlp_weight_grad_batch_workspace_bytes", "rr_mlp_weight_grad_batch", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_schedule", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
 
 _lib = None
@@ -85,6 +90,8 @@ def lib():
         L.rr_pipeline_step_to.argtypes = [C.c_void_p, C.POINTER(RRState), C.POINTER(RRState), C.c_void_p, C.c_int32, C.POINTER(RROutputs)]
         L.rr_env_step_to.argtypes = [C.c_void_p, C.POINTER(RRState), C.POINTER(RRState), C.c_void_p, C.c_int32, C.POINTER(RREnvIO),
                                      C.c_void_p, C.POINTER(RROutputs)]
+        L.rr_env_unroll.argtypes = [C.c_void_p, C.POINTER(RRState), C.POINTER(RRState), C.c_void_p, C.c_int32, C.c_int32, C.POINTER(RREnvIO),
+                                    C.c_void_p, C.POINTER(RRUnrollIO)]
         L.rr_env_reset.argtypes = [C.c_void_p, C.POINTER(RRState), C.POINTER(RREnvIO), C.POINTER(RROutputs)]
         L.rr_debug_layout.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_int32)),
                                       C.POINTER(C.POINTER(C.c_int32))]
@@ -268,6 +275,18 @@ class Batch:
         _check(lib().rr_env_step_to(self.h, C.byref(self._state(st_in)), C.byref(self._state(st_out)),
                                     _ptr(action, numel=self.N * self.dims.nu), int(n_frames), C.byref(self._env(env)),
                                     _ptr(cur_frame_in, torch.int32, self.N), C.byref(o) if o else None))
+
+    def env_unroll(self, st_in, st_out, actions, n_frames: int, env, cur_frame_in, first, first_obs, prev_done, steps_in, steps_out,
+                   truncation_out, episode_length: float):
+        """`actions.shape[0]` env steps with the Episode + AutoReset wrappers in one launch (C ABI `rr_env_unroll`)."""
+        T = actions.shape[0]
+        for t in (first_obs, prev_done, steps_in, steps_out, truncation_out):
+            _ptr(t)
+        w = RRUnrollIO(self._state(first), first_obs.data_ptr(), prev_done.data_ptr(), steps_in.data_ptr(), steps_out.data_ptr(),
+                       truncation_out.data_ptr(), float(episode_length))
+        _check(lib().rr_env_unroll(self.h, C.byref(self._state(st_in)), C.byref(self._state(st_out)),
+                                   _ptr(actions, numel=T * self.N * self.dims.nu), T, int(n_frames), C.byref(self._env(env)),
+                                   _ptr(cur_frame_in, torch.int32, self.N), C.byref(w)))
 
     def env_reset(self, st, env, out=None):
         o = self._outputs(out)

@@ -127,6 +127,26 @@ int rr_pipeline_step_to(rr_batch* b, const rr_state* in, const rr_state* out_sta
 int rr_env_step_to(rr_batch* b, const rr_state* in, const rr_state* out_state, const float* action, int32_t n_frames,
                    const rr_env_io* env, const int32_t* cur_frame_in, const rr_outputs* out);
 
+/* A multi-step rollout in ONE launch: num_steps x [Rodent.step, then EpisodeWrapper + AutoResetWrapper with action_repeat 1] --
+ * the `lax.scan` over env.step of brax.training.acting.generate_unroll / a jitted random-action rollout [UP; REF
+ * brax_rodent_run_ppo.py:141-151].  actions [num_steps][N][nu].  The environments of the launch do not wait for each other between
+ * steps and the state stays on chip; results are those of num_steps calls of rr_env_step_to + rr_wrap_episode_autoreset, bit for
+ * bit.  `in` / `out_state` / `env` / `cur_frame_in` as rr_env_step_to (obs, reward, done, metrics, cur_frame of the LAST step are
+ * written); `wrap`: the stored first state and first observation (restored where an episode ends), the wrappers' state before the
+ * launch (prev_done, steps_in [N]) and after it (steps_out, truncation_out [N]; the final done goes to env->done).
+ * Production instance only (no rr_outputs); RR_EUNSUPPORTED for models without a multi-step instance and for the Newton solver. */
+typedef struct rr_unroll_io {
+  rr_state first;
+  const float* first_obs;
+  const float* prev_done;
+  const float* steps_in;
+  float* steps_out;
+  float* truncation_out;
+  float episode_length;
+} rr_unroll_io;
+int rr_env_unroll(rr_batch* b, const rr_state* in, const rr_state* out_state, const float* actions, int32_t num_steps, int32_t n_frames,
+                  const rr_env_io* env, const int32_t* cur_frame_in, const rr_unroll_io* wrap);
+
 /* obs of Rodent.reset: after rr_pipeline_init, obs = _get_obs(data, 0, cur_frame) [REF :89];
  * implemented as rr_pipeline_init + obs epilogue in one launch. Only env->obs/track_pos/cur_frame are used. */
 int rr_env_reset(rr_batch* b, const rr_state* st, const rr_env_io* env, const rr_outputs* out);

@@ -270,3 +270,46 @@ def test_graph_capture_next_to_an_rccl_communicator():
         p = ctx.Process(target=_nccl_graph_worker, args=(29731, out))
         p.start(); p.join(180)
         assert p.exitcode == 0 and out.get("ok") is True
+
+
+def test_multi_step_rollout_equals_single_steps():
+    """rr_env_unroll (T wrapped env steps in one launch, state on chip, Episode + AutoReset applied in place) leaves every leaf of
+    the state exactly as T calls of the wrapped step do -- through episode ends (episode_length 7), unhealthy terminations and
+    clip-frame saturation."""
+    from rodent_amd import envs, jax_random
+    from rodent_amd.envs import graphed, wrappers
+    dev = torch.device("cuda:0")
+    N, T = 96, 23
+    g = torch.Generator(device=dev).manual_seed(11)
+    acts = torch.rand(T, N, 30, device=dev, generator=g) * 2 - 1
+    keys = jax_random.split(jax_random.PRNGKey(8), N)
+
+    def make():
+        env = envs.get_environment("rodent", track_pos=util.synthetic_track(), num_envs=N, xml_path="rodent_optimized.xml", iterations=8,
+                                   ls_iterations=8, device=dev, healthy_z_range=(0.045, 0.5))
+        wenv = wrappers.wrap(env, episode_length=7, action_repeat=1)
+        return wenv, wenv.step(wenv.reset(keys), acts[0])
+    wenv, st = make()
+    want = st
+    for t in range(1, T):
+        want = wenv.step(want, acts[t])
+    wenv2, st2 = make()
+    got = wenv2.unroll(st2, acts[1:])
+    torch.cuda.synchronize()
+    assert float(want.info["steps"].max()) <= 7 and float((want.done > 0).float().sum()) >= 0
+    la, lb = graphed.tree_leaves(got), graphed.tree_leaves(want)
+    assert len(la) == len(lb)
+    for x, y in zip(la, lb):
+        assert x.shape == y.shape and torch.equal(x, y)
+    # chained launches (8 + 14 steps) give the same state
+    got2 = wenv2.unroll(wenv2.unroll(st2, acts[1:9]), acts[9:])
+    torch.cuda.synchronize()
+    for x, y in zip(graphed.tree_leaves(got2), lb):
+        assert torch.equal(x, y)
+    # configurations without a multi-step instance refuse loudly
+    env_n = envs.get_environment("rodent", track_pos=util.synthetic_track(), num_envs=8, xml_path="rodent_optimized.xml", iterations=4,
+                                 ls_iterations=8, solver="newton", device=dev)
+    wn = wrappers.wrap(env_n, episode_length=7, action_repeat=1)
+    sn = wn.step(wn.reset(keys[:8]), acts[0, :8])
+    with pytest.raises(RuntimeError, match="multi-step"):
+        wn.unroll(sn, acts[1:3, :8].contiguous())

@@ -35,7 +35,18 @@ for S in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
                     sub[3] = wenv.step(state, a)
     run(WARM)
     torch.cuda.synchronize()
-    if GRAPH:
+    UT = int(os.environ.get("RR_PROBE_UNROLL", "0"))
+    if UT:          # multi-step launches: UT wrapped steps per launch, actions drawn UT steps at a time
+        def run(k):
+            for _ in range(k // UT):
+                for sub, st in zip(subs, streams):
+                    with torch.cuda.stream(st):
+                        wenv, env, gen, state = sub
+                        a = torch.empty(UT, n, env.action_size, device=dev).uniform_(-1.0, 1.0, generator=gen)
+                        sub[3] = wenv.unroll(state, a)
+        run(2 * UT)
+        torch.cuda.synchronize()
+    elif GRAPH:
         def make(sub):
             wenv, env, gen, state = sub
 
@@ -69,7 +80,9 @@ for S in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     run(STEPS)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if GRAPH:
+    if GRAPH and not UT:
         assert all(torch.isfinite(g.state.obs).all() for g in gs)
-    print(json.dumps({"graph": GRAPH, "substreams": S, "envs_each": n, "env_steps_per_s": N * STEPS / dt, "ms_per_2048_env_step": dt / STEPS * 1e3}), flush=True)
+    else:
+        assert all(torch.isfinite(sub[3].obs).all() for sub in subs)
+    print(json.dumps({"graph": GRAPH and not UT, "unroll": UT, "substreams": S, "envs_each": n, "env_steps_per_s": N * STEPS / dt, "ms_per_2048_env_step": dt / STEPS * 1e3}), flush=True)
     del subs
