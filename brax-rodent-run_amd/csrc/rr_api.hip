@@ -257,8 +257,9 @@ static kern_t pick_kernel(const rr_model* m, bool prof = false, bool dbg = false
   return nullptr;
 }
 
-static kern_t pick_unroll_kernel(const rr_model* m) {
+static kern_t pick_unroll_kernel(const rr_model* m, bool actor = false) {
   if (m->solver == 2 || !(m->NBS == 2 && m->NVS == 2 && m->NCS == 1)) return nullptr;
+  if (actor) return RRDimsRodent::matches(m->kd) ? rr_step_kernel<2, 2, 1, false, false, RRDimsRodent, false, true, true> : nullptr;
   return RRDimsRodent::matches(m->kd) ? rr_step_kernel<2, 2, 1, false, false, RRDimsRodent, false, true> : rr_step_kernel<2, 2, 1, false, false, RRDims, false, true>;
 }
 
@@ -335,7 +336,8 @@ static int collect_timing(rr_batch* b, bool all = true) {
 }
 
 static int launch(rr_batch* b, const rr_state* st, const float* ctrl, int n_frames, const rr_env_io* env, const rr_outputs* out, int mode,
-                  const rr_state* st_in = nullptr, const int32_t* cur_frame_in = nullptr, const rr_unroll_io* un = nullptr, int unroll_T = 0) {
+                  const rr_state* st_in = nullptr, const int32_t* cur_frame_in = nullptr, const rr_unroll_io* un = nullptr, int unroll_T = 0,
+                  const rr_actor_io* ac = nullptr) {
   if (!b || !st || !st->qpos || !st->qvel || !st->act || !st->qacc_warmstart) return fail(RR_EINVAL, "launch: null state pointer");
   if (st_in && (!st_in->qpos || !st_in->qvel || !st_in->act || !st_in->qacc_warmstart)) return fail(RR_EINVAL, "launch: null input state pointer");
   if ((mode & 1) && (!ctrl || n_frames <= 0)) return fail(RR_EINVAL, "launch: step needs ctrl and n_frames > 0");
@@ -363,8 +365,18 @@ static int launch(rr_batch* b, const rr_state* st, const float* ctrl, int n_fram
   kern_t kern = pick_kernel(b->m, b->prof != nullptr, io.dbg != nullptr || io.o_cdist || io.o_cpos || io.o_cframe);
   if (un) {      // multi-step rollout: the UNROLL instance, no diagnostics
     if (b->prof || io.dbg || io.o_cdist || io.o_cpos || io.o_cframe || out) return fail(RR_EUNSUPPORTED, "rr_env_unroll: no diagnostic outputs in a multi-step rollout");
-    kern = pick_unroll_kernel(b->m);
+    kern = pick_unroll_kernel(b->m, ac != nullptr);
     if (!kern) return fail(RR_EUNSUPPORTED, "rr_env_unroll: no multi-step kernel instance for this model / solver");
+    if (ac) {
+      if (b->m->dims.obs_dim > 1280) return fail(RR_EUNSUPPORTED, "rr_env_unroll_policy: observation wider than 1280");
+      if (ac->nhidden < 1 || ac->nhidden > 5) return fail(RR_EUNSUPPORTED, "rr_env_unroll_policy: 1 .. 5 hidden layers");
+      io.a_obs_in = ac->obs_in; io.a_mean = ac->mean; io.a_std = ac->std; io.a_W0 = ac->w0; io.a_b0 = ac->b0;
+      for (int l = 1; l < ac->nhidden; ++l) { io.a_Wt[l - 1] = ac->hidden_wt[l - 1]; io.a_b[l - 1] = ac->hidden_b[l - 1]; }
+      io.a_Wth = ac->head_wt; io.a_bh = ac->head_b; io.a_noise = ac->noise; io.a_actions = ac->actions_out; io.ctrl = ac->actions_out;
+      io.t_obs = ac->traj_obs; io.t_raw = ac->traj_raw_action; io.t_logp = ac->traj_log_prob; io.t_reward = ac->traj_reward;
+      io.t_discount = ac->traj_discount; io.t_trunc = ac->traj_truncation; io.a_min_std = ac->min_std; io.a_nh = ac->nhidden;
+      io.obs = ac->traj_obs;
+    }
     io.first_qpos = un->first.qpos; io.first_qvel = un->first.qvel; io.first_act = un->first.act; io.first_warm = un->first.qacc_warmstart;
     io.first_obs = un->first_obs; io.prev_done = un->prev_done; io.steps_in = un->steps_in; io.steps_out = un->steps_out;
     io.trunc_out = un->truncation_out; io.episode_length = un->episode_length; io.unroll_T = unroll_T;
@@ -404,6 +416,22 @@ extern "C" int rr_env_unroll(rr_batch* b, const rr_state* in, const rr_state* ou
       !wrap->steps_in || !wrap->steps_out || !wrap->truncation_out)
     return fail(RR_EINVAL, "rr_env_unroll: null wrapper pointer");
   return launch(b, outst, actions, n_frames, env, nullptr, 1, in, cur_frame_in, wrap, num_steps);
+}
+extern "C" int rr_env_unroll_policy(rr_batch* b, const rr_state* in, const rr_state* outst, int32_t num_steps, int32_t n_frames, const rr_env_io* env,
+                                    const int32_t* cur_frame_in, const rr_unroll_io* wrap, const rr_actor_io* actor) {
+  if (!env || !in || !cur_frame_in || !wrap || !actor || num_steps <= 0) return fail(RR_EINVAL, "rr_env_unroll_policy: bad argument");
+  if (!wrap->first.qpos || !wrap->first.qvel || !wrap->first.act || !wrap->first.qacc_warmstart || !wrap->first_obs || !wrap->prev_done ||
+      !wrap->steps_in || !wrap->steps_out || !wrap->truncation_out)
+    return fail(RR_EINVAL, "rr_env_unroll_policy: null wrapper pointer");
+  if (!actor->obs_in || !actor->w0 || !actor->b0 || !actor->head_wt || !actor->head_b || !actor->noise || !actor->actions_out || !actor->traj_obs ||
+      !actor->traj_raw_action || !actor->traj_log_prob || !actor->traj_reward || !actor->traj_discount || !actor->traj_truncation ||
+      (actor->mean == nullptr) != (actor->std == nullptr))
+    return fail(RR_EINVAL, "rr_env_unroll_policy: null actor pointer");
+  for (int l = 1; l < actor->nhidden && l < 5; ++l)
+    if (!actor->hidden_wt[l - 1] || !actor->hidden_b[l - 1]) return fail(RR_EINVAL, "rr_env_unroll_policy: null hidden layer");
+  rr_env_io e = *env;
+  e.obs = actor->traj_obs;                   // the observations of the launch go to the trajectory
+  return launch(b, outst, actor->actions_out, n_frames, &e, nullptr, 1, in, cur_frame_in, wrap, num_steps, actor);
 }
 extern "C" int rr_pipeline_init(rr_batch* b, const rr_state* st, const rr_outputs* out) { return launch(b, st, nullptr, 1, nullptr, out, 0); }
 extern "C" int rr_pipeline_step(rr_batch* b, const rr_state* st, const float* ctrl, int32_t n_frames, const rr_outputs* out) {

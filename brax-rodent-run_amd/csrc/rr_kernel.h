@@ -140,6 +140,18 @@ struct RRIO {
   float *steps_out, *trunc_out;                                                // ... and after it
   float episode_length;
   int unroll_T;
+  // ... with the actor inside (ACTOR instances, rr_env_unroll_policy): the action of step t is sampled in-kernel from the policy MLP
+  // on the observation of step t, and the transitions go straight into the trajectory buffers [N][T(+1)][...] of the learner
+  const float *a_obs_in;                          // [N][obs]  observation of the state before the launch
+  const float *a_mean, *a_std;                    // nullable: observation normaliser
+  const float *a_W0, *a_b0;                       // first layer [32][obs] (torch layout), [32]
+  const float *a_Wt[4], *a_b[4];                  // hidden layers l = 1 .. a_nh-1: TRANSPOSED [32 in][32 out], [32]
+  const float *a_Wth, *a_bh;                      // head TRANSPOSED and padded [32 in][64], [64]
+  const float *a_noise;                           // [T][N][A] standard normal draws
+  float *a_actions;                               // [T][N][nu] out: the actions taken (also what the step reads as ctrl)
+  float *t_obs, *t_raw, *t_logp, *t_reward, *t_discount, *t_trunc;     // [N][T+1][obs], [N][T][A], [N][T] x 4
+  float a_min_std;
+  int a_nh;
   int mode;  // 0 = forward only (pipeline_init), 1 = step; bit 1 (2) = env epilogue as reset (obs only)
   int pad_;
 };
@@ -1809,11 +1821,74 @@ static __device__ __forceinline__ RRIO load_io() {
 #endif
 }
 
+// The actor of a multi-step rollout, one wave = one env: policy MLP (obs -> 32 x a_nh -> 2A, SiLU) on the observation of step `ut`,
+// tanh-normal sample with the given noise, action into a_actions (where the step reads its ctrl), raw action and log-prob into the
+// trajectory buffers.  First layer: lane l holds the normalised observation entries l, l+64, ..; for each of the 32 units the 64
+// partial dot products are summed over the wave (four units per DPP reduction).  Later layers: lane n = unit n, the activation
+// vector handed around by shuffles, weights transposed so that the lanes read consecutive floats.
+static __device__ __forceinline__ float rr_softplus_k(float x) { return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x))); }
+template <class DT>
+__device__ __forceinline__ void rr_actor_step(const RRIO& io, const DT& D, int lane, int env, int ut, int num_envs) {
+  constexpr int JM = 20;                      // observation entries per lane (host check: obs_dim <= 1280)
+  const int K = D.obs_dim, T = io.unroll_T, A = D.nu;
+  const float* ob = io.t_obs + ((size_t)env * (T + 1) + ut) * K;
+  float x[JM];
+#pragma unroll
+  for (int j = 0; j < JM; ++j) {
+    const int k = lane + RR_LANES * j, kc = k < K ? k : K - 1;
+    float v = ob[kc];
+    if (io.a_mean) v = (v - io.a_mean[kc]) / io.a_std[kc];
+    x[j] = k < K ? v : 0.0f;
+  }
+  float z1 = 0.0f;
+  for (int n0 = 0; n0 < 32; n0 += 4) {
+    float p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < JM; ++j) {
+      const int k = lane + RR_LANES * j, kc = k < K ? k : K - 1;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) p[u] = fmaf(x[j], io.a_W0[(size_t)(n0 + u) * K + kc], p[u]);
+    }
+    wave_sum_n<4>(p);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) z1 = lane == n0 + u ? p[u] : z1;
+  }
+  const int l32 = lane & 31;
+  float h = z1 + io.a_b0[l32];
+  h = h / (1.0f + expf(-h));
+#pragma unroll
+  for (int l = 1; l < 5; ++l) {             // constant indices into the kernel-argument arrays (they live in scalar registers)
+    if (l < io.a_nh) {
+      const float* wt = io.a_Wt[l - 1];
+      float acc = io.a_b[l - 1][l32];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) acc = fmaf(__shfl(h, k, RR_LANES), wt[k * 32 + l32], acc);
+      h = acc / (1.0f + expf(-acc));
+    }
+  }
+  float o = io.a_bh[lane];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) o = fmaf(__shfl(h, k, RR_LANES), io.a_Wth[k * 64 + lane], o);
+  const float s_raw = __shfl(o, (A + lane) & 63, RR_LANES);      // lane a: logits[A + a]
+  float lp = 0.0f;
+  if (lane < A) {
+    const float HALF_LOG_2PI = 0.91893853320467274178f, LOG2 = 0.69314718055994530942f;
+    const float scale = rr_softplus_k(s_raw) + io.a_min_std;
+    const float raw = o + scale * io.a_noise[((size_t)ut * num_envs + env) * A + lane];
+    const float zz = (raw - o) / scale;
+    lp = -0.5f * zz * zz - logf(scale) - HALF_LOG_2PI - 2.0f * (LOG2 - raw - rr_softplus_k(-2.0f * raw));
+    io.a_actions[((size_t)ut * num_envs + env) * A + lane] = tanhf(raw);
+    io.t_raw[((size_t)env * T + ut) * A + lane] = raw;
+  }
+  lp = wave_sum(lp);
+  if (lane == 0) io.t_logp[(size_t)env * T + ut] = lp;
+}
+
 // UNROLL: io.unroll_T env steps per launch.  The environments of a launch never wait for each other between steps (a synchronised
 // step lasts as long as its slowest environment; over ten unsynchronised steps the slowest SUM is 6.5 % below ten slowest steps,
 // tools/tail_probe.py), the state stays in LDS from step to step, and the Episode + AutoReset wrappers
 // (brax.envs.wrappers.training; rr_wrap_episode_autoreset is their one-launch form) are applied in place.
-template <int NBS, int NVS, int NCS, bool PROF, bool DBG, class DT, bool NEWTON = false, bool UNROLL = false>
+template <int NBS, int NVS, int NCS, bool PROF, bool DBG, class DT, bool NEWTON = false, bool UNROLL = false, bool ACTOR = false>
 __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(const RRDims Dk, const RRTables T, const RRIO io_kernarg, const int num_envs,
                                                            const int n_frames) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1854,6 +1929,12 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
  for (int ut = 0; ut < nsteps; ++ut) {
   if (UNROLL) { lane = opaque(lane); w.lane = lane; asm volatile("" : "+s"(env)); io = load_io(); }
   const size_t ctrl_at = UNROLL ? ((size_t)ut * num_envs + env) * D.nu : (size_t)env * D.nu;
+  if (ACTOR) {
+    if (ut == 0) {       // the observation the rollout starts from is row 0 of the env's trajectory
+      for (int i = lane; i < D.obs_dim; i += RR_LANES) io.t_obs[(size_t)env * (io.unroll_T + 1) * D.obs_dim + i] = io.a_obs_in[(size_t)env * D.obs_dim + i];
+    }
+    rr_actor_step(io, D, lane, env, ut, num_envs);
+  }
   // ---- load state (a multi-step rollout keeps it in LDS after its first step)
   if (!UNROLL || ut == 0) {
     for (int i = lane; i < D.nq; i += RR_LANES) w.s_qpos[i] = io.qpos_in[(size_t)env * D.nq + i];
@@ -1964,7 +2045,7 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
       if (io.o_cinert) for (int e = lane; e < 10 * D.nbody; e += RR_LANES) io.o_cinert[(size_t)env * 10 * D.nbody + e] = w.s_cinert[e];
       if (io.o_cvel) for (int e = lane; e < 6 * D.nbody; e += RR_LANES) io.o_cvel[(size_t)env * 6 * D.nbody + e] = w.s_cvel[e];
       if (io.obs) {
-        float* ob = io.obs + (size_t)env * D.obs_dim + D.nq + D.nv;
+        float* ob = (ACTOR ? io.t_obs + ((size_t)env * (io.unroll_T + 1) + ut + 1) * D.obs_dim : io.obs + (size_t)env * D.obs_dim) + D.nq + D.nv;
         for (int i = lane; i < 10 * (D.nbody - 1); i += RR_LANES) ob[i] = w.s_cinert[10 + i];
         ob += 10 * (D.nbody - 1);
         for (int i = lane; i < 6 * (D.nbody - 1); i += RR_LANES) ob[i] = w.s_cvel[6 + i];
@@ -2066,7 +2147,7 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
     const bool is_reset = (mode & 2) != 0;
     const int old_frame = UNROLL ? u_frame : io.cur_frame_in[env];
     const int new_frame = is_reset ? old_frame : old_frame + 1;
-    float* ob = io.obs + (size_t)env * D.obs_dim;
+    float* ob = ACTOR ? io.t_obs + ((size_t)env * (io.unroll_T + 1) + ut + 1) * D.obs_dim : io.obs + (size_t)env * D.obs_dim;
     int o = 0;
     for (int i = lane; i < D.nq; i += RR_LANES) ob[o + i] = w.s_qpos[i];
     o += D.nq;
@@ -2096,13 +2177,18 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
       if (lane == 0) {
         int fi = old_frame < 0 ? 0 : (old_frame > io.track_len - 1 ? io.track_len - 1 : old_frame);
         const v3 dx = ld3(w.s_qpos) - ld3(io.track_pos + 3 * fi);
-        const float pos_reward = expf(-100.0f * sqrtf(dot(dx, dx)));
+        // explicit roundings (no fused multiply-add left to the optimiser): every instance of the kernel -- single step, multi-step,
+        // actor inside -- must form the reward identically, bit for bit
+        const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx.x, dx.x), __fmul_rn(dx.y, dx.y)), __fmul_rn(dx.z, dx.z));
+        const float pos_reward = expf(__fmul_rn(-100.0f, sqrtf(d2)));
         const float z = w.s_qpos[2];
         float healthy = z < io.z_min ? 0.0f : 1.0f;
         if (z > io.z_max) healthy = 0.0f;
-        const float hr = io.terminate_when_unhealthy ? io.healthy_reward : io.healthy_reward * healthy;
-        const float cc = io.ctrl_cost_weight * a2;
-        io.reward[env] = pos_reward + hr - cc;
+        const float hr = io.terminate_when_unhealthy ? io.healthy_reward : __fmul_rn(io.healthy_reward, healthy);
+        const float cc = __fmul_rn(io.ctrl_cost_weight, a2);     // explicit roundings: every instance of the kernel forms the reward identically
+        const float rew = __fsub_rn(__fadd_rn(pos_reward, hr), cc);   // (left to the optimiser, one instance fused the product into the sum: 1 ulp)
+        io.reward[env] = rew;
+        if (ACTOR) io.t_reward[(size_t)env * io.unroll_T + ut] = rew;
         io.done[env] = io.terminate_when_unhealthy ? 1.0f - healthy : 0.0f;
         io.metrics[3 * env] = pos_reward; io.metrics[3 * env + 1] = -cc; io.metrics[3 * env + 2] = hr;
         io.cur_frame[env] = new_frame;
@@ -2120,6 +2206,7 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
       const float done2 = over ? 1.0f : done_env, trunc = over ? 1.0f - done_env : 0.0f;
       u_prev_done = done2;
       u_frame = new_frame;
+      if (ACTOR && lane == 0) { io.t_discount[(size_t)env * io.unroll_T + ut] = 1.0f - done2; io.t_trunc[(size_t)env * io.unroll_T + ut] = trunc; }
       if (__builtin_amdgcn_readfirstlane(__float_as_int(done2)) != 0) {
         w.sync();
         for (int i = lane; i < D.nq; i += RR_LANES) w.s_qpos[i] = io.first_qpos[(size_t)env * D.nq + i];

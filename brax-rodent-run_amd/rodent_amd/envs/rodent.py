@@ -125,6 +125,33 @@ class Rodent(PipelineEnv):
         m.update(pos_reward=metrics[:, 0], reward_quadctrl=metrics[:, 1], reward_alive=metrics[:, 2])
         return state.replace(pipeline_state=PipelineState(**st), obs=obs, reward=reward, done=done, metrics=m, info=ninfo)
 
+    def unroll_policy_wrapped(self, state: State, episode_length: float, actor: dict, noise: torch.Tensor, traj: dict) -> State:
+        """`generate_unroll` in one launch (`rr_env_unroll_policy`): T = noise.shape[0] x [policy(obs) -> tanh-normal sample -> step ->
+        EpisodeWrapper + AutoResetWrapper], the transitions written into `traj` (views of the learner's buffers, batch-major).
+        `actor`: the policy's parameters as the kernel takes them (`acting.actor_params`).  Returns the state after the last step."""
+        if self._pipeline_outputs or self._contact_outputs:
+            raise ValueError("a multi-step rollout returns no pipeline / contact outputs: build the env without them")
+        N, dev, T = self.num_envs, self.device, noise.shape[0]
+        ps, info = state.pipeline_state, state.info
+        fps = info["first_pipeline_state"]
+        st_in = dict(qpos=ps.qpos, qvel=ps.qvel, act=ps.act, qacc_warmstart=ps.qacc_warmstart)
+        first = dict(qpos=fps.qpos, qvel=fps.qvel, act=fps.act, qacc_warmstart=fps.qacc_warmstart)
+        st = {k: torch.empty_like(v) for k, v in st_in.items()}
+        cur_frame = torch.empty_like(info["cur_frame"])
+        reward, done, steps, trunc = (torch.empty(N, device=dev) for _ in range(4))
+        metrics = torch.empty(N, 3, device=dev)
+        actions = torch.empty(T, N, self.action_size, device=dev)
+        obs_in = state.obs.contiguous()            # (also fills the env io's obs slot, which this entry point does not write)
+        self._batch.env_unroll_policy(st_in, st, T, self._n_frames, self._env_io(cur_frame, obs_in, reward, done, metrics), info["cur_frame"],
+                                      first, info["first_obs"], state.done, info["steps"], steps, trunc, episode_length, actor, noise, actions,
+                                      traj, obs_in)
+        ninfo = dict(info)
+        ninfo.update(cur_frame=cur_frame, steps=steps, truncation=trunc)
+        m = dict(state.metrics)
+        m.update(pos_reward=metrics[:, 0], reward_quadctrl=metrics[:, 1], reward_alive=metrics[:, 2])
+        obs = traj["obs"].reshape(N, T + 1, -1)[:, T].contiguous()
+        return state.replace(pipeline_state=PipelineState(**st), obs=obs, reward=reward, done=done, metrics=m, info=ninfo), actions
+
     def step(self, state: State, action: torch.Tensor) -> State:
         """Runs one timestep of the environment's dynamics."""
         N, dev, s = self.num_envs, self.device, self.sys

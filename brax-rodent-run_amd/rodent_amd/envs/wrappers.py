@@ -176,6 +176,13 @@ class FusedEpisodeAutoResetWrapper(Wrapper):
         return base.unroll_wrapped(state, actions, self.episode_length)
 
 
+    def unroll_policy(self, state, actor, noise, traj):
+        """`acting.generate_unroll` in one launch: see `Rodent.unroll_policy_wrapped` (C ABI `rr_env_unroll_policy`).
+        Returns (state after the last step, actions taken [T, N, nu])."""
+        base = self.env.unwrapped if hasattr(self.env, "unwrapped") else self.env
+        return base.unroll_policy_wrapped(state, self.episode_length, actor, noise, traj)
+
+
 def wrap(env, episode_length: int = 1000, action_repeat: int = 1):
     """brax.envs.wrappers.training.wrap: Vmap -> Episode -> AutoReset (one fused wrapper for a HIP env with
     action_repeat 1; RR_FUSED_WRAPPERS=0 selects the composition)."""

@@ -47,6 +47,12 @@ class RRUnrollIO(C.Structure):
                 ("truncation_out", C.c_void_p), ("episode_length", C.c_float)]
 
 
+class RRActorIO(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("obs_in", "mean", "std", "w0", "b0")] + [("hidden_wt", C.c_void_p * 4), ("hidden_b", C.c_void_p * 4)] + \
+        [(n, C.c_void_p) for n in ("head_wt", "head_b", "noise", "actions_out", "traj_obs", "traj_raw_action", "traj_log_prob", "traj_reward",
+                                   "traj_discount", "traj_truncation")] + [("min_std", C.c_float), ("nhidden", C.c_int32)]
+
+
 class RRDwItem(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("delta", "act", "act_rows", "mean", "std", "delta_colsum")] + \
         [("M", C.c_int32), ("O", C.c_int32), ("I", C.c_int32), ("grad", C.c_void_p)]
@@ -58,7 +64,7 @@ class RRPpoCfg(C.Structure):
 
 
 EXPORTS = ["rr_model_load", "rr_model_dims", "rr_model_set_solver", "rr_model_set_solver_type", "rr_model_destroy", "rr_model_table", "rr_kernarg_layout", "rr_batch_create",
-           "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset", "rr_pipeline_step_to", "rr_env_step_to", "rr_env_unroll",
+           "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset", "rr_pipeline_step_to", "rr_env_step_to", "rr_env_unroll", "rr_env_unroll_policy",
            "rr_compute_gae", "rr_mlp_forward", "rr_ppo_loss_workspace_bytes", "rr_ppo_loss", "rr_policy_act_workspace_bytes", "rr_policy_act", "rr_policy_sample", "rr_policy_backward_workspace_bytes", "rr_policy_backward", "rr_mlp_silu_backward_workspace_bytes", "rr_mlp_silu_backward", "rr_mlp_value_backward_workspace_bytes", "rr_mlp_value_backward", "rr_mlp_weight_grad_workspace_bytes", "rr_mlp_weight_grad", "rr_mlp_weight_grad_batch_workspace_bytes", "rr_mlp_weight_grad_batch", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_schedule", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
 
 _lib = None
@@ -92,6 +98,8 @@ def lib():
                                      C.c_void_p, C.POINTER(RROutputs)]
         L.rr_env_unroll.argtypes = [C.c_void_p, C.POINTER(RRState), C.POINTER(RRState), C.c_void_p, C.c_int32, C.c_int32, C.POINTER(RREnvIO),
                                     C.c_void_p, C.POINTER(RRUnrollIO)]
+        L.rr_env_unroll_policy.argtypes = [C.c_void_p, C.POINTER(RRState), C.POINTER(RRState), C.c_int32, C.c_int32, C.POINTER(RREnvIO), C.c_void_p,
+                                           C.POINTER(RRUnrollIO), C.POINTER(RRActorIO)]
         L.rr_env_reset.argtypes = [C.c_void_p, C.POINTER(RRState), C.POINTER(RREnvIO), C.POINTER(RROutputs)]
         L.rr_debug_layout.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_int32)),
                                       C.POINTER(C.POINTER(C.c_int32))]
@@ -287,6 +295,32 @@ class Batch:
         _check(lib().rr_env_unroll(self.h, C.byref(self._state(st_in)), C.byref(self._state(st_out)),
                                    _ptr(actions, numel=T * self.N * self.dims.nu), T, int(n_frames), C.byref(self._env(env)),
                                    _ptr(cur_frame_in, torch.int32, self.N), C.byref(w)))
+
+    def env_unroll_policy(self, st_in, st_out, T: int, n_frames: int, env, cur_frame_in, first, first_obs, prev_done, steps_in, steps_out,
+                          truncation_out, episode_length: float, actor: dict, noise, actions_out, traj: dict, obs_in):
+        """T x [policy -> sample -> wrapped env step] with the transitions recorded, one launch (C ABI `rr_env_unroll_policy`).
+        actor: mean, std (or None), w0, b0, hidden_wt / hidden_b (lists, transposed weights), head_wt, head_b (padded), min_std;
+        traj: obs [N, T+1, K], raw_action [N, T, A], log_prob / reward / discount / truncation [N, T] (contiguous views)."""
+        for t in (first_obs, prev_done, steps_in, steps_out, truncation_out, noise, actions_out, obs_in, actor["w0"], actor["b0"],
+                  actor["head_wt"], actor["head_b"], *actor["hidden_wt"], *actor["hidden_b"], *traj.values()):
+            _ptr(t)
+        nh = len(actor["hidden_wt"]) + 1
+        A_, K = self.dims.nu, self.dims.obs_dim
+        if (noise.numel() != T * self.N * A_ or actions_out.numel() != T * self.N * A_ or traj["obs"].numel() != self.N * (T + 1) * K
+                or traj["raw_action"].numel() != self.N * T * A_ or any(traj[k].numel() != self.N * T for k in ("log_prob", "reward", "discount", "truncation"))
+                or actor["w0"].shape != (32, K) or actor["head_wt"].shape != (32, 64) or actor["head_b"].numel() != 64):
+            raise ValueError("rr_env_unroll_policy: inconsistent shapes")
+        w = RRUnrollIO(self._state(first), first_obs.data_ptr(), prev_done.data_ptr(), steps_in.data_ptr(), steps_out.data_ptr(),
+                       truncation_out.data_ptr(), float(episode_length))
+        p = lambda t: t.data_ptr() if t is not None else None
+        a = RRActorIO(obs_in.data_ptr(), p(actor.get("mean")), p(actor.get("std")), actor["w0"].data_ptr(), actor["b0"].data_ptr(),
+                      (C.c_void_p * 4)(*([t.data_ptr() for t in actor["hidden_wt"]] + [None] * (4 - nh + 1))),
+                      (C.c_void_p * 4)(*([t.data_ptr() for t in actor["hidden_b"]] + [None] * (4 - nh + 1))),
+                      actor["head_wt"].data_ptr(), actor["head_b"].data_ptr(), noise.data_ptr(), actions_out.data_ptr(), traj["obs"].data_ptr(),
+                      traj["raw_action"].data_ptr(), traj["log_prob"].data_ptr(), traj["reward"].data_ptr(), traj["discount"].data_ptr(),
+                      traj["truncation"].data_ptr(), float(actor["min_std"]), nh)
+        _check(lib().rr_env_unroll_policy(self.h, C.byref(self._state(st_in)), C.byref(self._state(st_out)), int(T), int(n_frames),
+                                          C.byref(self._env(env)), _ptr(cur_frame_in, torch.int32, self.N), C.byref(w), C.byref(a)))
 
     def env_reset(self, st, env, out=None):
         o = self._outputs(out)

@@ -48,6 +48,48 @@ def generate_unroll(env, state, policy: Callable, buf: UnrollBuffer, u: int, gen
     return state
 
 
+def actor_params(policy_net, normalizer_params, min_std: float) -> dict:
+    """The policy's parameters in the layout of the in-kernel actor (`rr_env_unroll_policy`): first layer as torch holds it, hidden
+    weights transposed, head transposed and zero-padded to 64 outputs.  Copies: call again after the parameters change."""
+    layers = list(policy_net.layers)
+    dev = layers[0].weight.device
+    P = layers[-1].out_features
+    head_wt = torch.zeros(32, 64, device=dev)
+    head_wt[:, :P] = layers[-1].weight.detach().t()
+    head_b = torch.zeros(64, device=dev)
+    head_b[:P] = layers[-1].bias.detach()
+    out = dict(w0=layers[0].weight.detach().contiguous(), b0=layers[0].bias.detach().contiguous(),
+               hidden_wt=[l.weight.detach().t().contiguous() for l in layers[1:-1]], hidden_b=[l.bias.detach().contiguous() for l in layers[1:-1]],
+               head_wt=head_wt, head_b=head_b, min_std=min_std, mean=None, std=None)
+    if normalizer_params is not None:
+        out.update(mean=normalizer_params.mean.contiguous(), std=normalizer_params.std.contiguous())
+    return out
+
+
+def fused_unroll_supported(wenv, policy_net, dist) -> bool:
+    """The one-launch unroll needs the fused wrapper of a HIP rodent env (rollout configuration) and the default policy shape."""
+    from .. import hip
+    from . import fused_mlp
+    base = wenv.unwrapped if hasattr(wenv, "unwrapped") else wenv
+    return (isinstance(wenv, wrappers.FusedEpisodeAutoResetWrapper) and hasattr(base, "unroll_policy_wrapped") and base.device.type == "cuda"
+            and not base._pipeline_outputs and not base._contact_outputs and getattr(getattr(base, "sys", None), "solver", "cg") == "cg"
+            and fused_mlp.fusable(policy_net, fused_mlp.POLICY_HIDDEN, 64) and 2 <= len(policy_net.layers) <= 5
+            and policy_net.layers[-1].out_features == 2 * dist.event_size and dist.event_size == base.action_size <= 32
+            and base.observation_size <= 1280)
+
+
+@torch.no_grad()
+def generate_unroll_fused(wenv, state, actor: dict, buf: UnrollBuffer, u: int, generator=None):
+    """`generate_unroll` as ONE launch (policy, sampling, env steps, wrappers and the recording of the transitions all inside the
+    multi-step kernel): the envs of the batch never wait for each other between the T steps."""
+    N, T = buf.N, buf.T
+    noise = torch.randn(T, N, buf.raw_action.shape[-1], device=buf.obs.device, generator=generator)
+    traj = dict(obs=buf.obs[u], raw_action=buf.raw_action[u], log_prob=buf.log_prob[u], reward=buf.reward[u], discount=buf.discount[u],
+                truncation=buf.truncation[u])
+    state, _ = wenv.unroll_policy(state, actor, noise, traj)
+    return state
+
+
 class SubBatchRollout:
     """The rank's N envs collected as S sub-batches of N / S envs, each with its own env batch, HIP stream, wrapper state and
     sampling generator; one unroll of a sub-batch (T x [policy forward, sampling, fused env step, wrapper kernel, buffer

@@ -170,6 +170,9 @@ def train(
             torch.cuda.synchronize(device)
 
     rollout_policy = {"fn": None, "norm": None}
+    # rollouts as one launch per unroll (rr_env_unroll_policy) where the env / policy shapes allow; RR_FUSED_ROLLOUT=0 keeps per-step launches
+    fused_rollout = (sub_rollout is None and action_repeat == 1 and os.environ.get("RR_FUSED_ROLLOUT", "1") == "1"
+                     and acting.fused_unroll_supported(wenv, policy_net, dist))
     gstate = {"graph": None, "graph_b": None, "calls": 0, "idx": None, "norm": None, "metrics": None, "failed": False}
 
     def adv_stats(adv):
@@ -275,6 +278,10 @@ def train(
             for u in range(U):
                 sub_rollout.unroll(rollout_policy["fn"], buf, u)
             sub_rollout.join()
+        elif fused_rollout:                              # generate_unroll as ONE launch per unroll: the actor runs inside the kernel
+            actor = acting.actor_params(policy_net, normalizer_params if normalize_observations else None, dist.min_std)
+            for u in range(U):
+                env_state = acting.generate_unroll_fused(wenv, env_state, actor, buf, u, gen)
         else:
             policy = make_policy(current_params())
             for u in range(U):

@@ -147,6 +147,29 @@ typedef struct rr_unroll_io {
 int rr_env_unroll(rr_batch* b, const rr_state* in, const rr_state* out_state, const float* actions, int32_t num_steps, int32_t n_frames,
                   const rr_env_io* env, const int32_t* cur_frame_in, const rr_unroll_io* wrap);
 
+/* rr_env_unroll with the actor inside: brax.training.acting.generate_unroll -- num_steps x [policy(obs) -> sample -> wrapped env
+ * step], transitions recorded -- in ONE launch [UP acting.generate_unroll / actor_step; SURVEY.md a22, a23].  Per env and step the
+ * wave evaluates the policy MLP (obs -> 32 x nhidden -> 2A, SiLU; optional normaliser) on the observation of that step, samples
+ * the tanh-normal action with the given noise, steps, applies the wrappers, and writes the transition into the learner's trajectory
+ * arrays: traj_obs [N][T+1][obs] (row t = observation of step t, row T = the bootstrap observation), traj_raw_action [N][T][A],
+ * traj_log_prob / traj_reward / traj_discount (= 1 - done) / traj_truncation [N][T]; actions_out [T][N][A] receives tanh(raw).
+ * Weights: w0 [32][obs] and b0 [32] as torch holds them; hidden_wt[l-1] (l = 1 .. nhidden-1) TRANSPOSED [32 in][32 out];
+ * head_wt TRANSPOSED and zero-padded to [32][64], head_b padded to [64]; noise [T][N][A] standard normal draws.
+ * The final observation is traj_obs[:, T] (env->obs is not written).  Instance for the rodent dimensions only. */
+typedef struct rr_actor_io {
+  const float* obs_in; const float* mean; const float* std;
+  const float* w0; const float* b0;
+  const float* hidden_wt[4]; const float* hidden_b[4];
+  const float* head_wt; const float* head_b;
+  const float* noise;
+  float* actions_out;
+  float* traj_obs; float* traj_raw_action; float* traj_log_prob; float* traj_reward; float* traj_discount; float* traj_truncation;
+  float min_std;
+  int32_t nhidden;
+} rr_actor_io;
+int rr_env_unroll_policy(rr_batch* b, const rr_state* in, const rr_state* out_state, int32_t num_steps, int32_t n_frames, const rr_env_io* env,
+                         const int32_t* cur_frame_in, const rr_unroll_io* wrap, const rr_actor_io* actor);
+
 /* obs of Rodent.reset: after rr_pipeline_init, obs = _get_obs(data, 0, cur_frame) [REF :89];
  * implemented as rr_pipeline_init + obs epilogue in one launch. Only env->obs/track_pos/cur_frame are used. */
 int rr_env_reset(rr_batch* b, const rr_state* st, const rr_env_io* env, const rr_outputs* out);

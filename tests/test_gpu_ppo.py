@@ -187,3 +187,67 @@ def test_autograd_free_learner_trains_like_the_autograd_path(monkeypatch):
     assert float(diff.max()) <= 2 * k * lr
     for name in loss["0"]:
         assert abs(loss["1"][name] - loss["0"][name]) <= 5e-3 * max(abs(loss["0"][name]), 1e-2), name
+
+
+def test_one_launch_unroll_with_the_actor_inside():
+    """rr_env_unroll_policy (policy MLP, sampling, T wrapped env steps and the recording of the transitions in one launch):
+    (1) replaying the recorded actions through the per-step path reproduces every recorded observation, discount, truncation and
+    the final state bit for bit (the reward to one ulp); (2) the recorded raw actions / log-probs are those of the two-launch actor
+    (rr_policy_act) on the recorded observations with the same noise, to float32 rounding."""
+    from rodent_amd import envs, hip, jax_random
+    from rodent_amd.envs import graphed, wrappers
+    from rodent_amd.training import acting, fused_mlp, networks, running_statistics
+    dev = torch.device("cuda:0")
+    N, T = 64, 9
+    torch.manual_seed(3)
+
+    def make():
+        env = envs.get_environment("rodent", track_pos=util.synthetic_track(), num_envs=N, xml_path="rodent_optimized.xml", iterations=8,
+                                   ls_iterations=8, device=dev, healthy_z_range=(0.045, 0.5))
+        wenv = wrappers.wrap(env, episode_length=5, action_repeat=1)
+        return env, wenv, wenv.reset(jax_random.split(jax_random.PRNGKey(2), N))
+    env, wenv, st0 = make()
+    nets = networks.make_ppo_networks(env.observation_size, env.action_size, device=dev)
+    net, dist = nets.policy_network, nets.parametric_action_distribution
+    for l in net.layers:
+        l.bias.data.uniform_(-0.3, 0.3)
+    norm = running_statistics.init_state(env.observation_size, dev)
+    norm.mean.copy_(torch.randn(env.observation_size, device=dev) * 0.05)
+    norm.std.copy_(torch.rand(env.observation_size, device=dev) + 0.7)
+    assert acting.fused_unroll_supported(wenv, net, dist)
+    buf = acting.UnrollBuffer(2, N, T, env.observation_size, env.action_size, dev)
+    actor = acting.actor_params(net, norm, dist.min_std)
+    noise = torch.randn(T, N, env.action_size, device=dev)
+    traj = dict(obs=buf.obs[1], raw_action=buf.raw_action[1], log_prob=buf.log_prob[1], reward=buf.reward[1], discount=buf.discount[1],
+                truncation=buf.truncation[1])
+    got, actions = wenv.unroll_policy(st0, actor, noise, traj)
+    torch.cuda.synchronize()
+    assert torch.isfinite(buf.obs[1]).all() and torch.isfinite(buf.log_prob[1]).all()
+    # (1) physics + wrappers: replay the recorded actions step by step
+    env2, wenv2, st = make()
+    for t in range(T):
+        assert torch.equal(buf.obs[1, :, t], st.obs), t
+        st = wenv2.step(st, actions[t])
+        # the reward's exp() is expanded differently inside the actor instance: the last bit of pos_reward may differ
+        assert (buf.reward[1, :, t] - st.reward).abs().max() <= 2.5e-7 and torch.equal(buf.discount[1, :, t], 1 - st.done), t
+        assert torch.equal(buf.truncation[1, :, t], st.info["truncation"]), t
+    assert torch.equal(buf.obs[1, :, T], st.obs)
+    assert float(buf.truncation[1].sum()) > 0                          # episodes of 5 steps: the reset path ran
+    la, lb = graphed.tree_leaves(got), graphed.tree_leaves(st)
+    assert len(la) == len(lb)
+    nexact = 0
+    for x, y in zip(la, lb):
+        assert x.shape == y.shape
+        if not torch.equal(x, y):                # reward and its pos_reward metric: one ulp (see above); everything else exact
+            assert x.dim() == 1 and (x - y).abs().max() <= 2.5e-7
+            nexact += 1
+    assert nexact <= 2
+    assert torch.equal(got.pipeline_state.qpos, st.pipeline_state.qpos) and torch.equal(got.obs, st.obs) and torch.equal(got.done, st.done)
+    # (2) the actor: same noise through the two-launch actor on the recorded observations
+    obs_t = buf.obs[1, :, :T].transpose(0, 1).reshape(T * N, -1).contiguous()
+    act, raw, lp, _ = hip.policy_act(obs_t, norm.mean, norm.std, fused_mlp.net_params(net), noise.reshape(T * N, -1).contiguous(), dist.min_std)
+    raw_k = buf.raw_action[1].transpose(0, 1).reshape(T * N, -1)
+    lp_k = buf.log_prob[1].transpose(0, 1).reshape(-1)
+    assert (raw_k - raw).abs().max() <= 2e-5 * max(1.0, float(raw.abs().max()))
+    assert (actions.reshape(T * N, -1) - act).abs().max() <= 2e-5
+    assert (lp_k - lp).abs().max() <= 2e-3
