@@ -259,7 +259,7 @@ static kern_t pick_kernel(const rr_model* m, bool prof = false, bool dbg = false
 
 static kern_t pick_unroll_kernel(const rr_model* m, bool actor = false) {
   if (m->solver == 2 || !(m->NBS == 2 && m->NVS == 2 && m->NCS == 1)) return nullptr;
-  if (actor) return RRDimsRodent::matches(m->kd) ? rr_step_kernel<2, 2, 1, false, false, RRDimsRodent, false, true, true> : nullptr;
+  if (actor) return RRDimsRodent::matches(m->kd) ? rr_step_kernel<2, 2, 1, false, false, RRDimsRodent, false, true, true> : rr_step_kernel<2, 2, 1, false, false, RRDims, false, true, true>;
   return RRDimsRodent::matches(m->kd) ? rr_step_kernel<2, 2, 1, false, false, RRDimsRodent, false, true> : rr_step_kernel<2, 2, 1, false, false, RRDims, false, true>;
 }
 
@@ -408,6 +408,10 @@ extern "C" int rr_env_step_to(rr_batch* b, const rr_state* in, const rr_state* o
   if (!env) return fail(RR_EINVAL, "rr_env_step_to: env io required");
   if (!in || !cur_frame_in) return fail(RR_EINVAL, "rr_env_step_to: null input state");
   return launch(b, outst, action, n_frames, env, out, 1, in, cur_frame_in);
+}
+extern "C" int rr_batch_unroll_supported(const rr_batch* b, int32_t with_actor) {
+  if (!b) return fail(RR_EINVAL, "rr_batch_unroll_supported: null batch");
+  return pick_unroll_kernel(b->m, with_actor != 0) ? 1 : 0;
 }
 extern "C" int rr_env_unroll(rr_batch* b, const rr_state* in, const rr_state* outst, const float* actions, int32_t num_steps, int32_t n_frames,
                              const rr_env_io* env, const int32_t* cur_frame_in, const rr_unroll_io* wrap) {

@@ -64,7 +64,7 @@ class RRPpoCfg(C.Structure):
 
 
 EXPORTS = ["rr_model_load", "rr_model_dims", "rr_model_set_solver", "rr_model_set_solver_type", "rr_model_destroy", "rr_model_table", "rr_kernarg_layout", "rr_batch_create",
-           "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset", "rr_pipeline_step_to", "rr_env_step_to", "rr_env_unroll", "rr_env_unroll_policy",
+           "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset", "rr_pipeline_step_to", "rr_env_step_to", "rr_batch_unroll_supported", "rr_env_unroll", "rr_env_unroll_policy",
            "rr_compute_gae", "rr_mlp_forward", "rr_ppo_loss_workspace_bytes", "rr_ppo_loss", "rr_policy_act_workspace_bytes", "rr_policy_act", "rr_policy_sample", "rr_policy_backward_workspace_bytes", "rr_policy_backward", "rr_mlp_silu_backward_workspace_bytes", "rr_mlp_silu_backward", "rr_mlp_value_backward_workspace_bytes", "rr_mlp_value_backward", "rr_mlp_weight_grad_workspace_bytes", "rr_mlp_weight_grad", "rr_mlp_weight_grad_batch_workspace_bytes", "rr_mlp_weight_grad_batch", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_schedule", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
 
 _lib = None
@@ -96,6 +96,7 @@ def lib():
         L.rr_pipeline_step_to.argtypes = [C.c_void_p, C.POINTER(RRState), C.POINTER(RRState), C.c_void_p, C.c_int32, C.POINTER(RROutputs)]
         L.rr_env_step_to.argtypes = [C.c_void_p, C.POINTER(RRState), C.POINTER(RRState), C.c_void_p, C.c_int32, C.POINTER(RREnvIO),
                                      C.c_void_p, C.POINTER(RROutputs)]
+        L.rr_batch_unroll_supported.argtypes = [C.c_void_p, C.c_int32]
         L.rr_env_unroll.argtypes = [C.c_void_p, C.POINTER(RRState), C.POINTER(RRState), C.c_void_p, C.c_int32, C.c_int32, C.POINTER(RREnvIO),
                                     C.c_void_p, C.POINTER(RRUnrollIO)]
         L.rr_env_unroll_policy.argtypes = [C.c_void_p, C.POINTER(RRState), C.POINTER(RRState), C.c_int32, C.c_int32, C.POINTER(RREnvIO), C.c_void_p,
@@ -283,6 +284,9 @@ class Batch:
         _check(lib().rr_env_step_to(self.h, C.byref(self._state(st_in)), C.byref(self._state(st_out)),
                                     _ptr(action, numel=self.N * self.dims.nu), int(n_frames), C.byref(self._env(env)),
                                     _ptr(cur_frame_in, torch.int32, self.N), C.byref(o) if o else None))
+
+    def unroll_supported(self, with_actor: bool = False) -> bool:
+        return _check(lib().rr_batch_unroll_supported(self.h, int(with_actor))) == 1
 
     def env_unroll(self, st_in, st_out, actions, n_frames: int, env, cur_frame_in, first, first_obs, prev_done, steps_in, steps_out,
                    truncation_out, episode_length: float):

@@ -75,7 +75,7 @@ def fused_unroll_supported(wenv, policy_net, dist) -> bool:
             and not base._pipeline_outputs and not base._contact_outputs and getattr(getattr(base, "sys", None), "solver", "cg") == "cg"
             and fused_mlp.fusable(policy_net, fused_mlp.POLICY_HIDDEN, 64) and 2 <= len(policy_net.layers) <= 5
             and policy_net.layers[-1].out_features == 2 * dist.event_size and dist.event_size == base.action_size <= 32
-            and base.observation_size <= 1280)
+            and base.observation_size <= 1280 and base._batch.unroll_supported(with_actor=True))
 
 
 @torch.no_grad()

@@ -135,6 +135,8 @@ int rr_env_step_to(rr_batch* b, const rr_state* in, const rr_state* out_state, c
  * written); `wrap`: the stored first state and first observation (restored where an episode ends), the wrappers' state before the
  * launch (prev_done, steps_in [N]) and after it (steps_out, truncation_out [N]; the final done goes to env->done).
  * Production instance only (no rr_outputs); RR_EUNSUPPORTED for models without a multi-step instance and for the Newton solver. */
+/* 1 when this batch's model / solver has a multi-step kernel instance (with_actor != 0: the one with the actor inside), else 0. */
+int rr_batch_unroll_supported(const rr_batch* b, int32_t with_actor);
 typedef struct rr_unroll_io {
   rr_state first;
   const float* first_obs;
@@ -155,7 +157,7 @@ int rr_env_unroll(rr_batch* b, const rr_state* in, const rr_state* out_state, co
  * traj_log_prob / traj_reward / traj_discount (= 1 - done) / traj_truncation [N][T]; actions_out [T][N][A] receives tanh(raw).
  * Weights: w0 [32][obs] and b0 [32] as torch holds them; hidden_wt[l-1] (l = 1 .. nhidden-1) TRANSPOSED [32 in][32 out];
  * head_wt TRANSPOSED and zero-padded to [32][64], head_b padded to [64]; noise [T][N][A] standard normal draws.
- * The final observation is traj_obs[:, T] (env->obs is not written).  Instance for the rodent dimensions only. */
+ * The final observation is traj_obs[:, T] (env->obs is not written).  Instances for the single-rodent models (rr_batch_unroll_supported). */
 typedef struct rr_actor_io {
   const float* obs_in; const float* mean; const float* std;
   const float* w0; const float* b0;

@@ -251,3 +251,20 @@ def test_one_launch_unroll_with_the_actor_inside():
     assert (raw_k - raw).abs().max() <= 2e-5 * max(1.0, float(raw.abs().max()))
     assert (actions.reshape(T * N, -1) - act).abs().max() <= 2e-5
     assert (lp_k - lp).abs().max() <= 2e-3
+
+
+def test_fused_rollout_on_a_model_without_the_fixed_dimension_instance():
+    """ppo.train's one-launch unrolls on rodent_new.xml (other contact / dof counts than rodent_optimized: the generic-dimension
+    instance of the multi-step kernel) -- the configuration examples/rodent_run_ppo.py runs."""
+    from rodent_amd import envs
+    from rodent_amd.envs import wrappers
+    from rodent_amd.training import acting
+    from rodent_amd.training.agents.ppo import train as ppo
+    env = envs.get_environment("rodent", track_pos=util.synthetic_track(), num_envs=64, xml_path="rodent_new.xml", iterations=8,
+                               ls_iterations=8, device="cuda:0")
+    assert env._batch.unroll_supported(with_actor=True) and env._batch.unroll_supported(with_actor=False)
+    log = []
+    _, params, _ = ppo.train(environment=env, num_timesteps=10 ** 9, episode_length=150, num_envs=64, batch_size=64, num_minibatches=4,
+                             unroll_length=5, num_updates_per_batch=2, num_evals=2, num_eval_envs=0, learning_rate=5e-5, entropy_cost=1e-3,
+                             discounting=0.97, normalize_observations=True, seed=1, max_training_steps=2, progress_fn=lambda n, m: log.append(m))
+    assert math.isfinite(float(log[-1]["training/total_loss"])) and float(params[0].count) == 64 * 4 * 5 * 2
