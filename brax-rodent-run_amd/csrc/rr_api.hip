@@ -705,7 +705,8 @@ static DwPlan dw_plan(int M, int O, int I) {
   p.ti = O <= 32 ? 128 : (O <= 64 ? 64 : 128);
   p.kc = O <= 32 ? 64 : (O <= 64 ? 32 : 16);             // equal matrix-core work per LDS hand-off in the three tile shapes
   const int tiles = ((O + p.to - 1) / p.to) * ((I + p.ti - 1) / p.ti);
-  const int want = std::max(1, std::min(512 / tiles, M / (2 * p.kc)));
+  static const int target = [] { const char* e = getenv("RR_DW_TARGET_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();   // workgroups per product
+  const int want = std::max(1, std::min(target / tiles, M / (2 * p.kc)));
   p.rows_per_slice = ((M + want - 1) / want + p.kc - 1) / p.kc * p.kc;
   p.nslice = (M + p.rows_per_slice - 1) / p.rows_per_slice;
   return p;
