@@ -1840,18 +1840,24 @@ __device__ __forceinline__ void rr_actor_step(const RRIO& io, const DT& D, int l
     if (io.a_mean) v = (v - io.a_mean[kc]) / io.a_std[kc];
     x[j] = k < K ? v : 0.0f;
   }
+  // all 32 units at once: every observation entry meets 32 independent loads (one per unit, 256 contiguous bytes each across the
+  // wave), so the memory system always has a full batch in flight; the 32 wave sums follow, four per DPP reduction
+  float p[32];
+#pragma unroll
+  for (int n = 0; n < 32; ++n) p[n] = 0.0f;
+#pragma unroll 2
+  for (int j = 0; j < JM; ++j) {
+    const int k = lane + RR_LANES * j, kc = k < K ? k : K - 1;
+    const float xj = x[j];
+#pragma unroll
+    for (int n = 0; n < 32; ++n) p[n] = fmaf(xj, io.a_W0[(size_t)n * K + kc], p[n]);
+  }
   float z1 = 0.0f;
+#pragma unroll
   for (int n0 = 0; n0 < 32; n0 += 4) {
-    float p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    wave_sum_n<4>(p + n0);
 #pragma unroll
-    for (int j = 0; j < JM; ++j) {
-      const int k = lane + RR_LANES * j, kc = k < K ? k : K - 1;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) p[u] = fmaf(x[j], io.a_W0[(size_t)(n0 + u) * K + kc], p[u]);
-    }
-    wave_sum_n<4>(p);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) z1 = lane == n0 + u ? p[u] : z1;
+    for (int u = 0; u < 4; ++u) z1 = lane == n0 + u ? p[n0 + u] : z1;
   }
   const int l32 = lane & 31;
   float h = z1 + io.a_b0[l32];
