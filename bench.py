@@ -118,9 +118,9 @@ def parse():
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5), help="BASELINE.json config (2 = the headline metric's)")
     ap.add_argument("--num-envs", type=int, default=None, help="envs per GPU (default 2048; 4096 for config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--substreams", type=int, default=2, help="config 2: the envs of a GPU are stepped as this many sub-batches on separate "
+    ap.add_argument("--substreams", type=int, default=1, help="config 2: the envs of a GPU are stepped as this many sub-batches on separate "
                     "HIP streams (one sub-batch's slowest envs overlap the others' bulk); 1 = one launch per step")
-    ap.add_argument("--unroll", type=int, default=5, help="config 2: env steps per launch (rr_env_unroll: the wrapped step scanned inside the kernel, "
+    ap.add_argument("--unroll", type=int, default=250, help="config 2: env steps per launch (rr_env_unroll: the wrapped step scanned inside the kernel, "
                     "actions drawn for that many steps at a time); 1 = one launch per step (HIP-graph replay unless --no-graph)")
     ap.add_argument("--no-graph", action="store_true", help="config 2: issue every step from the host instead of replaying a HIP graph of it")
     ap.add_argument("--solver", default="cg", choices=("cg", "newton"), help="config 2 only; the headline configuration is cg 8/8")
@@ -260,8 +260,9 @@ def main():
                 # multi-step launches: the rollout's scan over the wrapped step runs INSIDE the kernel (envs never wait for each other between
                 # steps, state on chip, wrappers in place; bit-identical to the per-step calls: tests/test_gpu_env.py)
                 workload = (f"{model}.xml random-action rollout, Rodent.step through Episode(150)+AutoReset wrappers, "
-                            f"{args.solver.upper()} {args.iterations}/{args.ls_iterations}, n_frames 10; {S_} sub-batches of {n_sub} envs on {S_} streams, "
-                            f"{UT_} env steps per launch (rr_env_unroll)")
+                            f"{args.solver.upper()} {args.iterations}/{args.ls_iterations}, n_frames 10; "
+                            + (f"{S_} sub-batches of {n_sub} envs on {S_} streams, " if S_ > 1 else "")
+                            + f"{UT_} env steps per launch (rr_env_unroll: the rollout's scan inside the kernel)")
                 args.no_graph = True
 
                 def unroll_steps(k):

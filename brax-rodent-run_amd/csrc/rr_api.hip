@@ -375,6 +375,8 @@ static int launch(rr_batch* b, const rr_state* st, const float* ctrl, int n_fram
       io.a_Wth = ac->head_wt; io.a_bh = ac->head_b; io.a_noise = ac->noise; io.a_actions = ac->actions_out; io.ctrl = ac->actions_out;
       io.t_obs = ac->traj_obs; io.t_raw = ac->traj_raw_action; io.t_logp = ac->traj_log_prob; io.t_reward = ac->traj_reward;
       io.t_discount = ac->traj_discount; io.t_trunc = ac->traj_truncation; io.a_min_std = ac->min_std; io.a_nh = ac->nhidden;
+      io.a_seg = ac->segment_length > 0 ? ac->segment_length : unroll_T;
+      if (unroll_T % io.a_seg) return fail(RR_EINVAL, "rr_env_unroll_policy: num_steps must be a multiple of segment_length");
       io.obs = ac->traj_obs;
     }
     io.first_qpos = un->first.qpos; io.first_qvel = un->first.qvel; io.first_act = un->first.act; io.first_warm = un->first.qacc_warmstart;

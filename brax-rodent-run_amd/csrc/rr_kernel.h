@@ -152,6 +152,7 @@ struct RRIO {
   float *t_obs, *t_raw, *t_logp, *t_reward, *t_discount, *t_trunc;     // [N][T+1][obs], [N][T][A], [N][T] x 4
   float a_min_std;
   int a_nh;
+  int a_seg, a_pad;                               // trajectory segment length L (unroll_T = U * L): the buffers are [U][N][L(+1)][...]
   int mode;  // 0 = forward only (pipeline_init), 1 = step; bit 1 (2) = env epilogue as reset (obs only)
   int pad_;
 };
@@ -1826,12 +1827,18 @@ static __device__ __forceinline__ RRIO load_io() {
 // trajectory buffers.  First layer: lane l holds the normalised observation entries l, l+64, ..; for each of the 32 units the 64
 // partial dot products are summed over the wave (four units per DPP reduction).  Later layers: lane n = unit n, the activation
 // vector handed around by shuffles, weights transposed so that the lanes read consecutive floats.
+// trajectory addressing: step s of the launch is step t = s % L of segment u = s / L; rows [u][env][t]
+struct RRTraj { int u, t; };
+static __device__ __forceinline__ RRTraj rr_traj(const RRIO& io, int s) { RRTraj r; r.u = s / io.a_seg; r.t = s - r.u * io.a_seg; return r; }
+static __device__ __forceinline__ size_t rr_traj_obs(const RRIO& io, int N, int env, int u, int t) { return ((size_t)u * N + env) * (io.a_seg + 1) + t; }   // row index
+static __device__ __forceinline__ size_t rr_traj_at(const RRIO& io, int N, int env, int s) { const RRTraj r = rr_traj(io, s); return ((size_t)r.u * N + env) * io.a_seg + r.t; }
 static __device__ __forceinline__ float rr_softplus_k(float x) { return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x))); }
 template <class DT>
 __device__ __forceinline__ void rr_actor_step(const RRIO& io, const DT& D, int lane, int env, int ut, int num_envs) {
   constexpr int JM = 20;                      // observation entries per lane (host check: obs_dim <= 1280)
-  const int K = D.obs_dim, T = io.unroll_T, A = D.nu;
-  const float* ob = io.t_obs + ((size_t)env * (T + 1) + ut) * K;
+  const int K = D.obs_dim, A = D.nu;
+  const RRTraj tr = rr_traj(io, ut);
+  const float* ob = io.t_obs + rr_traj_obs(io, num_envs, env, tr.u, tr.t) * K;
   float x[JM];
 #pragma unroll
   for (int j = 0; j < JM; ++j) {
@@ -1884,10 +1891,10 @@ __device__ __forceinline__ void rr_actor_step(const RRIO& io, const DT& D, int l
     const float zz = (raw - o) / scale;
     lp = -0.5f * zz * zz - logf(scale) - HALF_LOG_2PI - 2.0f * (LOG2 - raw - rr_softplus_k(-2.0f * raw));
     io.a_actions[((size_t)ut * num_envs + env) * A + lane] = tanhf(raw);
-    io.t_raw[((size_t)env * T + ut) * A + lane] = raw;
+    io.t_raw[rr_traj_at(io, num_envs, env, ut) * A + lane] = raw;
   }
   lp = wave_sum(lp);
-  if (lane == 0) io.t_logp[(size_t)env * T + ut] = lp;
+  if (lane == 0) io.t_logp[rr_traj_at(io, num_envs, env, ut)] = lp;
 }
 
 // UNROLL: io.unroll_T env steps per launch.  The environments of a launch never wait for each other between steps (a synchronised
@@ -1937,7 +1944,7 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
   const size_t ctrl_at = UNROLL ? ((size_t)ut * num_envs + env) * D.nu : (size_t)env * D.nu;
   if (ACTOR) {
     if (ut == 0) {       // the observation the rollout starts from is row 0 of the env's trajectory
-      for (int i = lane; i < D.obs_dim; i += RR_LANES) io.t_obs[(size_t)env * (io.unroll_T + 1) * D.obs_dim + i] = io.a_obs_in[(size_t)env * D.obs_dim + i];
+      for (int i = lane; i < D.obs_dim; i += RR_LANES) io.t_obs[rr_traj_obs(io, num_envs, env, 0, 0) * D.obs_dim + i] = io.a_obs_in[(size_t)env * D.obs_dim + i];
     }
     rr_actor_step(io, D, lane, env, ut, num_envs);
   }
@@ -2051,7 +2058,7 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
       if (io.o_cinert) for (int e = lane; e < 10 * D.nbody; e += RR_LANES) io.o_cinert[(size_t)env * 10 * D.nbody + e] = w.s_cinert[e];
       if (io.o_cvel) for (int e = lane; e < 6 * D.nbody; e += RR_LANES) io.o_cvel[(size_t)env * 6 * D.nbody + e] = w.s_cvel[e];
       if (io.obs) {
-        float* ob = (ACTOR ? io.t_obs + ((size_t)env * (io.unroll_T + 1) + ut + 1) * D.obs_dim : io.obs + (size_t)env * D.obs_dim) + D.nq + D.nv;
+        float* ob = (ACTOR ? io.t_obs + rr_traj_obs(io, num_envs, env, rr_traj(io, ut).u, rr_traj(io, ut).t + 1) * D.obs_dim : io.obs + (size_t)env * D.obs_dim) + D.nq + D.nv;
         for (int i = lane; i < 10 * (D.nbody - 1); i += RR_LANES) ob[i] = w.s_cinert[10 + i];
         ob += 10 * (D.nbody - 1);
         for (int i = lane; i < 6 * (D.nbody - 1); i += RR_LANES) ob[i] = w.s_cvel[6 + i];
@@ -2153,7 +2160,7 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
     const bool is_reset = (mode & 2) != 0;
     const int old_frame = UNROLL ? u_frame : io.cur_frame_in[env];
     const int new_frame = is_reset ? old_frame : old_frame + 1;
-    float* ob = ACTOR ? io.t_obs + ((size_t)env * (io.unroll_T + 1) + ut + 1) * D.obs_dim : io.obs + (size_t)env * D.obs_dim;
+    float* ob = ACTOR ? io.t_obs + rr_traj_obs(io, num_envs, env, rr_traj(io, ut).u, rr_traj(io, ut).t + 1) * D.obs_dim : io.obs + (size_t)env * D.obs_dim;
     int o = 0;
     for (int i = lane; i < D.nq; i += RR_LANES) ob[o + i] = w.s_qpos[i];
     o += D.nq;
@@ -2194,7 +2201,7 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
         const float cc = __fmul_rn(io.ctrl_cost_weight, a2);     // explicit roundings: every instance of the kernel forms the reward identically
         const float rew = __fsub_rn(__fadd_rn(pos_reward, hr), cc);   // (left to the optimiser, one instance fused the product into the sum: 1 ulp)
         io.reward[env] = rew;
-        if (ACTOR) io.t_reward[(size_t)env * io.unroll_T + ut] = rew;
+        if (ACTOR) io.t_reward[rr_traj_at(io, num_envs, env, ut)] = rew;
         io.done[env] = io.terminate_when_unhealthy ? 1.0f - healthy : 0.0f;
         io.metrics[3 * env] = pos_reward; io.metrics[3 * env + 1] = -cc; io.metrics[3 * env + 2] = hr;
         io.cur_frame[env] = new_frame;
@@ -2212,7 +2219,7 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
       const float done2 = over ? 1.0f : done_env, trunc = over ? 1.0f - done_env : 0.0f;
       u_prev_done = done2;
       u_frame = new_frame;
-      if (ACTOR && lane == 0) { io.t_discount[(size_t)env * io.unroll_T + ut] = 1.0f - done2; io.t_trunc[(size_t)env * io.unroll_T + ut] = trunc; }
+      if (ACTOR && lane == 0) { const size_t at = rr_traj_at(io, num_envs, env, ut); io.t_discount[at] = 1.0f - done2; io.t_trunc[at] = trunc; }
       if (__builtin_amdgcn_readfirstlane(__float_as_int(done2)) != 0) {
         w.sync();
         for (int i = lane; i < D.nq; i += RR_LANES) w.s_qpos[i] = io.first_qpos[(size_t)env * D.nq + i];
@@ -2220,6 +2227,13 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
         for (int i = lane; i < D.nu; i += RR_LANES) w.s_act[i] = io.first_act[(size_t)env * D.nu + i];
         for (int i = lane; i < D.obs_dim; i += RR_LANES) ob[i] = io.first_obs[(size_t)env * D.obs_dim + i];
         w.sync();
+      }
+      if (ACTOR) {      // the last observation of a segment is also the first of the next one (the learner's trajectories overlap by one row)
+        const RRTraj tr = rr_traj(io, ut);
+        if (tr.t + 1 == io.a_seg && ut + 1 < nsteps) {
+          float* nx = io.t_obs + rr_traj_obs(io, num_envs, env, tr.u + 1, 0) * D.obs_dim;
+          for (int i = lane; i < D.obs_dim; i += RR_LANES) nx[i] = ob[i];
+        }
       }
       if (ut == nsteps - 1) {
         if (lane == 0) { io.done[env] = done2; io.steps_out[env] = u_steps; io.trunc_out[env] = trunc; }

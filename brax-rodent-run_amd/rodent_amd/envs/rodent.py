@@ -125,10 +125,11 @@ class Rodent(PipelineEnv):
         m.update(pos_reward=metrics[:, 0], reward_quadctrl=metrics[:, 1], reward_alive=metrics[:, 2])
         return state.replace(pipeline_state=PipelineState(**st), obs=obs, reward=reward, done=done, metrics=m, info=ninfo)
 
-    def unroll_policy_wrapped(self, state: State, episode_length: float, actor: dict, noise: torch.Tensor, traj: dict) -> State:
+    def unroll_policy_wrapped(self, state: State, episode_length: float, actor: dict, noise: torch.Tensor, traj: dict, segment: int = 0) -> State:
         """`generate_unroll` in one launch (`rr_env_unroll_policy`): T = noise.shape[0] x [policy(obs) -> tanh-normal sample -> step ->
         EpisodeWrapper + AutoResetWrapper], the transitions written into `traj` (views of the learner's buffers, batch-major).
-        `actor`: the policy's parameters as the kernel takes them (`acting.actor_params`).  Returns the state after the last step."""
+        `actor`: the policy's parameters as the kernel takes them (`acting.actor_params`).  `segment` = L: the T steps are recorded as
+        T / L trajectories ([U, N, L(+1), ...] buffers) -- a whole rollout phase in one launch.  Returns the state after the last step."""
         if self._pipeline_outputs or self._contact_outputs:
             raise ValueError("a multi-step rollout returns no pipeline / contact outputs: build the env without them")
         N, dev, T = self.num_envs, self.device, noise.shape[0]
@@ -144,12 +145,13 @@ class Rodent(PipelineEnv):
         obs_in = state.obs.contiguous()            # (also fills the env io's obs slot, which this entry point does not write)
         self._batch.env_unroll_policy(st_in, st, T, self._n_frames, self._env_io(cur_frame, obs_in, reward, done, metrics), info["cur_frame"],
                                       first, info["first_obs"], state.done, info["steps"], steps, trunc, episode_length, actor, noise, actions,
-                                      traj, obs_in)
+                                      traj, obs_in, segment)
         ninfo = dict(info)
         ninfo.update(cur_frame=cur_frame, steps=steps, truncation=trunc)
         m = dict(state.metrics)
         m.update(pos_reward=metrics[:, 0], reward_quadctrl=metrics[:, 1], reward_alive=metrics[:, 2])
-        obs = traj["obs"].reshape(N, T + 1, -1)[:, T].contiguous()
+        L_ = segment or T
+        obs = traj["obs"].reshape(T // L_, N, L_ + 1, -1)[-1, :, L_].contiguous()
         return state.replace(pipeline_state=PipelineState(**st), obs=obs, reward=reward, done=done, metrics=m, info=ninfo), actions
 
     def step(self, state: State, action: torch.Tensor) -> State:

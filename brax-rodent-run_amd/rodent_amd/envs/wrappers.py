@@ -176,11 +176,11 @@ class FusedEpisodeAutoResetWrapper(Wrapper):
         return base.unroll_wrapped(state, actions, self.episode_length)
 
 
-    def unroll_policy(self, state, actor, noise, traj):
+    def unroll_policy(self, state, actor, noise, traj, segment: int = 0):
         """`acting.generate_unroll` in one launch: see `Rodent.unroll_policy_wrapped` (C ABI `rr_env_unroll_policy`).
         Returns (state after the last step, actions taken [T, N, nu])."""
         base = self.env.unwrapped if hasattr(self.env, "unwrapped") else self.env
-        return base.unroll_policy_wrapped(state, self.episode_length, actor, noise, traj)
+        return base.unroll_policy_wrapped(state, self.episode_length, actor, noise, traj, segment)
 
 
 def wrap(env, episode_length: int = 1000, action_repeat: int = 1):

@@ -50,7 +50,7 @@ class RRUnrollIO(C.Structure):
 class RRActorIO(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("obs_in", "mean", "std", "w0", "b0")] + [("hidden_wt", C.c_void_p * 4), ("hidden_b", C.c_void_p * 4)] + \
         [(n, C.c_void_p) for n in ("head_wt", "head_b", "noise", "actions_out", "traj_obs", "traj_raw_action", "traj_log_prob", "traj_reward",
-                                   "traj_discount", "traj_truncation")] + [("min_std", C.c_float), ("nhidden", C.c_int32)]
+                                   "traj_discount", "traj_truncation")] + [("min_std", C.c_float), ("nhidden", C.c_int32), ("segment_length", C.c_int32)]
 
 
 class RRDwItem(C.Structure):
@@ -301,16 +301,20 @@ class Batch:
                                    _ptr(cur_frame_in, torch.int32, self.N), C.byref(w)))
 
     def env_unroll_policy(self, st_in, st_out, T: int, n_frames: int, env, cur_frame_in, first, first_obs, prev_done, steps_in, steps_out,
-                          truncation_out, episode_length: float, actor: dict, noise, actions_out, traj: dict, obs_in):
+                          truncation_out, episode_length: float, actor: dict, noise, actions_out, traj: dict, obs_in, segment: int = 0):
         """T x [policy -> sample -> wrapped env step] with the transitions recorded, one launch (C ABI `rr_env_unroll_policy`).
         actor: mean, std (or None), w0, b0, hidden_wt / hidden_b (lists, transposed weights), head_wt, head_b (padded), min_std;
-        traj: obs [N, T+1, K], raw_action [N, T, A], log_prob / reward / discount / truncation [N, T] (contiguous views)."""
+        traj: obs [N, T+1, K], raw_action [N, T, A], log_prob / reward / discount / truncation [N, T] (contiguous views); with
+        `segment` = L < T: U = T / L such blocks ([U, N, L+1, K], ...), a whole rollout phase of U unrolls."""
         for t in (first_obs, prev_done, steps_in, steps_out, truncation_out, noise, actions_out, obs_in, actor["w0"], actor["b0"],
                   actor["head_wt"], actor["head_b"], *actor["hidden_wt"], *actor["hidden_b"], *traj.values()):
             _ptr(t)
         nh = len(actor["hidden_wt"]) + 1
         A_, K = self.dims.nu, self.dims.obs_dim
-        if (noise.numel() != T * self.N * A_ or actions_out.numel() != T * self.N * A_ or traj["obs"].numel() != self.N * (T + 1) * K
+        L_ = segment or T
+        if T % L_:
+            raise ValueError("rr_env_unroll_policy: the number of steps must be a multiple of the segment length")
+        if (noise.numel() != T * self.N * A_ or actions_out.numel() != T * self.N * A_ or traj["obs"].numel() != (T // L_) * self.N * (L_ + 1) * K
                 or traj["raw_action"].numel() != self.N * T * A_ or any(traj[k].numel() != self.N * T for k in ("log_prob", "reward", "discount", "truncation"))
                 or actor["w0"].shape != (32, K) or actor["head_wt"].shape != (32, 64) or actor["head_b"].numel() != 64):
             raise ValueError("rr_env_unroll_policy: inconsistent shapes")
@@ -322,7 +326,7 @@ class Batch:
                       (C.c_void_p * 4)(*([t.data_ptr() for t in actor["hidden_b"]] + [None] * (4 - nh + 1))),
                       actor["head_wt"].data_ptr(), actor["head_b"].data_ptr(), noise.data_ptr(), actions_out.data_ptr(), traj["obs"].data_ptr(),
                       traj["raw_action"].data_ptr(), traj["log_prob"].data_ptr(), traj["reward"].data_ptr(), traj["discount"].data_ptr(),
-                      traj["truncation"].data_ptr(), float(actor["min_std"]), nh)
+                      traj["truncation"].data_ptr(), float(actor["min_std"]), nh, int(L_))
         _check(lib().rr_env_unroll_policy(self.h, C.byref(self._state(st_in)), C.byref(self._state(st_out)), int(T), int(n_frames),
                                           C.byref(self._env(env)), _ptr(cur_frame_in, torch.int32, self.N), C.byref(w), C.byref(a)))
 

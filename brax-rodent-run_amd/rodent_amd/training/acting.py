@@ -90,6 +90,18 @@ def generate_unroll_fused(wenv, state, actor: dict, buf: UnrollBuffer, u: int, g
     return state
 
 
+@torch.no_grad()
+def generate_unrolls_fused(wenv, state, actor: dict, buf: UnrollBuffer, generator=None):
+    """ALL `buf.U` unrolls of a training step as one launch: the policy does not change during the rollout phase, so its U x T env
+    steps are one multi-step rollout recorded as U trajectories (`segment` = T).  Over U x T = 640 unsynchronised steps the envs'
+    costs average out (a synchronised step lasts as long as its slowest env)."""
+    U, N, T = buf.U, buf.N, buf.T
+    noise = torch.randn(U * T, N, buf.raw_action.shape[-1], device=buf.obs.device, generator=generator)
+    traj = dict(obs=buf.obs, raw_action=buf.raw_action, log_prob=buf.log_prob, reward=buf.reward, discount=buf.discount, truncation=buf.truncation)
+    state, _ = wenv.unroll_policy(state, actor, noise, traj, segment=T)
+    return state
+
+
 class SubBatchRollout:
     """The rank's N envs collected as S sub-batches of N / S envs, each with its own env batch, HIP stream, wrapper state and
     sampling generator; one unroll of a sub-batch (T x [policy forward, sampling, fused env step, wrapper kernel, buffer

@@ -280,8 +280,11 @@ def train(
             sub_rollout.join()
         elif fused_rollout:                              # generate_unroll as ONE launch per unroll: the actor runs inside the kernel
             actor = acting.actor_params(policy_net, normalizer_params if normalize_observations else None, dist.min_std)
-            for u in range(U):
-                env_state = acting.generate_unroll_fused(wenv, env_state, actor, buf, u, gen)
+            if os.environ.get("RR_FUSED_ROLLOUT_PHASE", "1") == "1":     # the whole rollout phase (U unrolls, same policy) as ONE launch
+                env_state = acting.generate_unrolls_fused(wenv, env_state, actor, buf, gen)
+            else:
+                for u in range(U):
+                    env_state = acting.generate_unroll_fused(wenv, env_state, actor, buf, u, gen)
         else:
             policy = make_policy(current_params())
             for u in range(U):

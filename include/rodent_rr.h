@@ -154,7 +154,8 @@ int rr_env_unroll(rr_batch* b, const rr_state* in, const rr_state* out_state, co
  * wave evaluates the policy MLP (obs -> 32 x nhidden -> 2A, SiLU; optional normaliser) on the observation of that step, samples
  * the tanh-normal action with the given noise, steps, applies the wrappers, and writes the transition into the learner's trajectory
  * arrays: traj_obs [N][T+1][obs] (row t = observation of step t, row T = the bootstrap observation), traj_raw_action [N][T][A],
- * traj_log_prob / traj_reward / traj_discount (= 1 - done) / traj_truncation [N][T]; actions_out [T][N][A] receives tanh(raw).
+ * traj_log_prob / traj_reward / traj_discount (= 1 - done) / traj_truncation [N][T] (with segment_length L < T: U = T / L such
+ * blocks one after the other -- a whole rollout phase of U unrolls in one launch); actions_out [T][N][A] receives tanh(raw).
  * Weights: w0 [32][obs] and b0 [32] as torch holds them; hidden_wt[l-1] (l = 1 .. nhidden-1) TRANSPOSED [32 in][32 out];
  * head_wt TRANSPOSED and zero-padded to [32][64], head_b padded to [64]; noise [T][N][A] standard normal draws.
  * The final observation is traj_obs[:, T] (env->obs is not written).  Instances for the single-rodent models (rr_batch_unroll_supported). */
@@ -168,6 +169,8 @@ typedef struct rr_actor_io {
   float* traj_obs; float* traj_raw_action; float* traj_log_prob; float* traj_reward; float* traj_discount; float* traj_truncation;
   float min_std;
   int32_t nhidden;
+  int32_t segment_length;   /* L: num_steps = U * L consecutive steps recorded as U trajectories, the traj_* arrays are [U][N][L(+1)][...]
+                             * and the last observation row of a segment is repeated as row 0 of the next; 0 = one segment (L = num_steps) */
 } rr_actor_io;
 int rr_env_unroll_policy(rr_batch* b, const rr_state* in, const rr_state* out_state, int32_t num_steps, int32_t n_frames, const rr_env_io* env,
                          const int32_t* cur_frame_in, const rr_unroll_io* wrap, const rr_actor_io* actor);

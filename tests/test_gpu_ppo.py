@@ -223,6 +223,17 @@ def test_one_launch_unroll_with_the_actor_inside():
     got, actions = wenv.unroll_policy(st0, actor, noise, traj)
     torch.cuda.synchronize()
     assert torch.isfinite(buf.obs[1]).all() and torch.isfinite(buf.log_prob[1]).all()
+    # the same T steps recorded as three trajectories of three steps (a whole rollout phase in one launch): same transitions
+    env3, wenv3, st3 = make()
+    buf3 = acting.UnrollBuffer(3, N, 3, env.observation_size, env.action_size, dev)
+    traj3 = dict(obs=buf3.obs, raw_action=buf3.raw_action, log_prob=buf3.log_prob, reward=buf3.reward, discount=buf3.discount, truncation=buf3.truncation)
+    got3, actions3 = wenv3.unroll_policy(st3, actor, noise, traj3, segment=3)
+    torch.cuda.synchronize()
+    assert torch.equal(actions3, actions) and torch.equal(got3.obs, got.obs) and torch.equal(got3.pipeline_state.qpos, got.pipeline_state.qpos)
+    for u in range(3):
+        assert torch.equal(buf3.obs[u], buf.obs[1, :, 3 * u:3 * u + 4]) and torch.equal(buf3.raw_action[u], buf.raw_action[1, :, 3 * u:3 * u + 3])
+        for name in ("log_prob", "reward", "discount", "truncation"):
+            assert torch.equal(getattr(buf3, name)[u], getattr(buf, name)[1, :, 3 * u:3 * u + 3]), name
     # (1) physics + wrappers: replay the recorded actions step by step
     env2, wenv2, st = make()
     for t in range(T):
