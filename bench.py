@@ -203,6 +203,9 @@ def main():
         extra = {"rollout_s_per_training_step": sum(t["rollout_s"] for t in timed) / len(timed),
                  "learner_s_per_training_step": sum(t["learner_s"] for t in timed) / len(timed),
                  "env_steps_per_training_step": env_steps_per_step}
+        # the rollout phase's launches carry many env steps each (the whole phase is one launch when the actor runs in-kernel): the
+        # roofline line is per env step of all envs = total step-kernel time / rollout steps per env (the reset launch counts ~0.1 %)
+        extra["rollout_steps_per_env"] = env_steps_per_step // (N * world) * len(times)
         workload = ("full PPO loop, launcher hyper-parameters (unroll 10, 64 minibatches x 8 epochs, lr 5e-5), rodent_optimized.xml, "
                     "CG 8/8, n_frames 10; step = one training step")
         batch = env._batch
@@ -366,10 +369,14 @@ def main():
         # config 2: `substreams` launches of N / substreams envs are in flight together, each lasting avg_kernel_s
         concurrent = extra.get("substreams", 1)
         per_launch = extra.get("env_steps_per_launch", 1)          # env steps of every env inside one launch
+        if args.config == 3 and launches and extra.get("step_kernel_time_source", "").startswith("hip events"):
+            per_launch = max(1.0, extra["rollout_steps_per_env"] / launches)
         achieved = bytes_per_env_step * (N // concurrent) * per_launch * concurrent / avg_kernel_s / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic() if args.config == 2 else None,
-                "kernel": "rr_step_kernel", "avg_kernel_ms": avg_kernel_s * 1e3, "launches": launches,
+                # avg_kernel_ms: kernel time of ONE bench step (all envs advance one step) = launch duration / env steps per launch
+                # (sub-batch launches run side by side); avg_launch_ms: the duration of a launch itself, as rocprofv3 lists it
+                "kernel": "rr_step_kernel", "avg_kernel_ms": avg_kernel_s * 1e3 / per_launch, "avg_launch_ms": avg_kernel_s * 1e3, "launches": launches,
                 "envs_per_launch": N // concurrent, "concurrent_launches": concurrent, "env_steps_per_launch": per_launch,
                 "algorithmic_bytes_per_env_step": bytes_per_env_step,
                 "limiter": "VALU issue + dependent LDS/L2 latency, not HBM (SURVEY.md 8(d)); see valu_busy_frac"}

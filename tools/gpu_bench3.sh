@@ -8,5 +8,5 @@ for cfg in "$@"; do
 import json
 d=json.loads(open('gpurun_out/b3_${tag}_s$1_u$2.json').read().strip().splitlines()[-1])
 r=d['roofline']
-print('substreams $1 unroll $2:', round(d['value']), 'env-steps/s  ms_per_step', round(d['ms_per_step'],4), ' kernel ms per launch', round(r['avg_kernel_ms'],4), 'launches', r['launches'], 'achieved', round(r['achieved'],2))"
+print('substreams $1 unroll $2:', round(d['value']), 'env-steps/s  ms_per_step', round(d['ms_per_step'],4), ' kernel ms per launch', round(r['avg_launch_ms'],4), 'launches', r['launches'], 'achieved', round(r['achieved'],2))"
 done
