@@ -252,6 +252,7 @@ def main():
                     for sub in subs:
                         with torch.cuda.stream(sub["stream"]):
                             sub["state"] = sub_step(sub, sub["state"])
+            single_steps = eager_steps
             workload = (f"{model}.xml random-action rollout, Rodent.step through Episode(150)+AutoReset wrappers, "
                         f"{args.solver.upper()} {args.iterations}/{args.ls_iterations}, n_frames 10; {S_} sub-batches of {n_sub} envs on {S_} streams, "
                         + ("host-issued steps" if args.no_graph else "HIP-graph replay of the step"))
@@ -318,6 +319,14 @@ def main():
             total_env_steps = N * world * args.steps
             elapsed = float(np.median(repeats_ms)) * args.steps * 1e-3
             extra = {"substreams": S_, "steps_per_graph_replay": None if args.no_graph else R_, "env_steps_per_launch": UT_}
+            if UT_ > 1:      # for the record, outside the timed region: the same rollout as one synchronised launch per step (Rodent.step per call)
+                for sub in subs:
+                    sub["env"]._batch.set_timing(False)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                single_steps(50)
+                torch.cuda.synchronize(dev)
+                extra["ms_per_step_one_launch_per_step"] = (time.perf_counter() - t1) / 50 * 1e3
         else:
             # ---- config 5: rodent_pair.xml (two replicated rodents, nv 146, 114 contacts), physics only (pipeline_step)
             from rodent_amd import assets, hip, mjcf
