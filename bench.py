@@ -260,6 +260,8 @@ def main():
             torch.cuda.synchronize(dev)
             R_ = 1
             UT_ = max(r for r in range(1, max(args.unroll, 1) + 1) if args.steps % r == 0)      # env steps per launch
+            if UT_ > 1 and not all(sub["env"]._batch.unroll_supported() for sub in subs):          # e.g. the Newton instance: one launch per step
+                UT_ = 1
             if UT_ > 1:
                 # multi-step launches: the rollout's scan over the wrapped step runs INSIDE the kernel (envs never wait for each other between
                 # steps, state on chip, wrappers in place; bit-identical to the per-step calls: tests/test_gpu_env.py)

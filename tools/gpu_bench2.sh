@@ -4,7 +4,7 @@ tag=$1; shift; mkdir -p gpurun_out
 for cfg in "$@"; do
   set -- $cfg
   flags="--substreams $1"; [ "$2" = "0" ] && flags="$flags --no-graph"
-  timeout -k 10 300 python3 bench.py --steps 300 --warmup 50 --no-cpu-baseline $flags > gpurun_out/b2_${tag}_s$1_g$2.json 2> gpurun_out/b2_${tag}_s$1_g$2.err || { echo "bench failed: $cfg"; tail -n 12 gpurun_out/b2_${tag}_s$1_g$2.err; exit 1; }
+  timeout -k 10 300 python3 bench.py --steps 300 --warmup 50 --no-cpu-baseline --unroll 1 $flags > gpurun_out/b2_${tag}_s$1_g$2.json 2> gpurun_out/b2_${tag}_s$1_g$2.err || { echo "bench failed: $cfg"; tail -n 12 gpurun_out/b2_${tag}_s$1_g$2.err; exit 1; }
   python3 -c "
 import json
 d=json.loads(open('gpurun_out/b2_${tag}_s$1_g$2.json').read().strip().splitlines()[-1])
