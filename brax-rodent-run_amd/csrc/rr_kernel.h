@@ -23,6 +23,12 @@
 #define RR_RING 8    // rows of a level schedule in flight (ktables RING); 12 / 16 measured 2-3 % slower in round 2
 
 #define RR_NPH 24    // phases of the diagnostic (s_memtime) build
+#ifndef RR_ENV_PRIO
+#define RR_ENV_PRIO 1      // graded wave priority by contacts in penetration (see the kernel body)
+#endif
+#ifndef RR_FACTOR_PRIO
+#define RR_FACTOR_PRIO 1   // top priority during the level schedules
+#endif
 #ifndef RR_DPP_BLOCK
 #define RR_DPP_BLOCK 1     // one s_nop per row-broadcast stage instead of one per value (-0.6 % launch time, bit-identical)
 #endif
@@ -446,6 +452,10 @@ struct Wave {
   }
   // wave priority of the throughput-bound phases: by the environment's weight (contacts in penetration), see the kernel body
   __device__ __forceinline__ void env_prio() const {
+#if !RR_ENV_PRIO
+    __builtin_amdgcn_s_setprio(0);
+    return;
+#endif
     if (jnact >= 12) __builtin_amdgcn_s_setprio(3);          // (s_setprio takes an immediate)
     else if (jnact >= 6) __builtin_amdgcn_s_setprio(2);
     else if (jnact >= 2) __builtin_amdgcn_s_setprio(1);
@@ -2097,7 +2107,9 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
     // ... and by phase: the two level schedules are one long dependent chain of LDS round trips that issues little; at top priority
     // its instructions go out the moment they are ready (-1.2 ... -1.6 % launch time; the same for the solves, the line-search
     // iterations or the tree sweeps measured +0.3 ... +0.6 % each and +3 % together)
+#if RR_FACTOR_PRIO
     __builtin_amdgcn_s_setprio(3);
+#endif
     w.factor();
     if (dg) for (int e = lane; e < D.nM; e += RR_LANES) dg[D.g_qLD + e] = w.s_qLD[2 * e];
     w.invert();
