@@ -122,6 +122,8 @@ def parse():
                     "HIP streams (one sub-batch's slowest envs overlap the others' bulk); 1 = one launch per step")
     ap.add_argument("--unroll", type=int, default=250, help="config 2: env steps per launch (rr_env_unroll: the wrapped step scanned inside the kernel, "
                     "actions drawn for that many steps at a time); 1 = one launch per step (HIP-graph replay unless --no-graph)")
+    ap.add_argument("--balance", action="store_true", help="config 2: pair the costliest envs of the previous launch with the cheapest on a SIMD "
+                    "(rr_batch_set_schedule); result-neutral")
     ap.add_argument("--no-graph", action="store_true", help="config 2: issue every step from the host instead of replaying a HIP graph of it")
     ap.add_argument("--solver", default="cg", choices=("cg", "newton"), help="config 2 only; the headline configuration is cg 8/8")
     ap.add_argument("--iterations", type=int, default=8)
@@ -236,7 +238,7 @@ def main():
                 with torch.cuda.stream(st):
                     env = envs.get_environment("rodent", track_pos=synthetic_track(), num_envs=n_sub, xml_path=f"{model}.xml",
                                                terminate_when_unhealthy=True, solver=args.solver, iterations=args.iterations,
-                                               ls_iterations=args.ls_iterations, device=dev)
+                                               ls_iterations=args.ls_iterations, device=dev, balance=args.balance, rebalance_every=1)
                     wenv = wrappers.wrap(env, episode_length=150, action_repeat=1)
                     g_ = torch.Generator(device=dev)
                     g_.manual_seed(1234 + 64 * rank + si)

@@ -1942,6 +1942,7 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
   const int nsteps = UNROLL ? io.unroll_T : 1;
   float u_steps = 0.0f, u_prev_done = 0.0f;
   int u_frame = 0;
+  unsigned u_work = 0;
   if (UNROLL) {
     u_steps = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(io.steps_in[env])));
     u_prev_done = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(io.prev_done[env])));
@@ -2151,7 +2152,8 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
   asm volatile("" : "+s"(env));
   io = load_io();
   if (PROF && io.prof && lane == 0) for (int i = 0; i < RR_NPH; ++i) io.prof[(size_t)env * RR_NPH + i] = w.pt[i];
-  if (io.cost && lane == 0) io.cost[env] = (unsigned)w.work;
+  if (UNROLL) u_work += (unsigned)w.work;        // a multi-step launch reports the work of all its steps
+  if (io.cost && lane == 0) io.cost[env] = UNROLL ? u_work : (unsigned)w.work;
   // ---- write back state (a multi-step rollout writes it once, after the wrappers of its last step: see below)
   if (!UNROLL) {
     for (int i = lane; i < D.nq; i += RR_LANES) io.qpos[(size_t)env * D.nq + i] = w.s_qpos[i];

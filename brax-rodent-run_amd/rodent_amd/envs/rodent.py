@@ -117,6 +117,7 @@ class Rodent(PipelineEnv):
         reward, done, steps, trunc = (torch.empty(N, device=dev) for _ in range(4))
         metrics = torch.empty(N, 3, device=dev)
         actions = actions.to(dev, torch.float32).contiguous()
+        self._rebalance()
         self._batch.env_unroll(st_in, st, actions, self._n_frames, self._env_io(cur_frame, obs, reward, done, metrics), info["cur_frame"],
                                first, info["first_obs"], state.done, info["steps"], steps, trunc, episode_length)
         ninfo = dict(info)
