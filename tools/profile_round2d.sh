@@ -7,7 +7,7 @@ mkdir -p $out
 export TMPDIR=/tmp OMP_NUM_THREADS=16
 echo "== bench config 2"; timeout -k 10 300 python3 bench.py > $out/bench_cfg2.json 2> $out/bench_cfg2.err; tail -c 1400 $out/bench_cfg2.json
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt --output-format csv -- python3 $root/bench.py --steps 100 --warmup 20 --no-cpu-baseline > $out/kt.log 2>&1 || echo "kernel-trace failed"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt --output-format csv -- python3 $root/bench.py --no-cpu-baseline > $out/kt.log 2>&1 || echo "kernel-trace failed"
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/fetch -o f --output-format csv -- python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --substreams 1 --no-graph --unroll 1 > $out/fetch.log 2>&1 || echo "fetch failed"
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/write -o w --output-format csv -- python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --substreams 1 --no-graph --unroll 1 > $out/write.log 2>&1 || echo "write failed"
 cd $root
