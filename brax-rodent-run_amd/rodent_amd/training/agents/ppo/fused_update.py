@@ -28,6 +28,10 @@ class FusedUpdate:
         dev = policy_net.layers[0].weight.device
         self.trange = torch.arange(unroll_length + 1, device=dev)
         self.bufs = {}
+        # the policy network's backward (35 us chain, small products) runs on a second stream next to the value network's (the
+        # matrix-core kernels that fill the GPU): fork / join through events, inside a HIP-graph capture as well.  RR_LEARNER_STREAMS=0: one stream
+        import os
+        self.side = torch.cuda.Stream(dev) if dev.type == "cuda" and os.environ.get("RR_LEARNER_STREAMS", "1") == "1" else None
         for p in list(policy_net.parameters()) + list(value_net.parameters()):
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
@@ -75,6 +79,14 @@ class FusedUpdate:
         noise = torch.randn(T * B, A, device=obs.device, dtype=obs.dtype, generator=generator)     # the draw of dist.entropy
         g_pol, g_val, metrics = hip.ppo_loss(pol, val, data, idx, noise, T, out=self.bufs, **self.cfg)
         n = T * B                                                                           # the bootstrap rows carry no policy gradient
-        items = self._policy_backward(ppre, g_pol[:n], obs, rows[:n], mean, std) + self._value_backward(vpre, g_val, obs, rows, mean, std)
-        hip.mlp_weight_grad_batch(items)            # all eleven dW = delta' h: one launch per tile shape + one reduction launch
+        if self.side is None:
+            items = self._policy_backward(ppre, g_pol[:n], obs, rows[:n], mean, std) + self._value_backward(vpre, g_val, obs, rows, mean, std)
+            hip.mlp_weight_grad_batch(items)        # all eleven dW = delta' h: one launch per tile shape + one reduction launch
+        else:
+            cur = torch.cuda.current_stream(obs.device)
+            self.side.wait_stream(cur)              # fork: the policy branch needs the forward's dumps and the loss gradients
+            with torch.cuda.stream(self.side):
+                hip.mlp_weight_grad_batch(self._policy_backward(ppre, g_pol[:n], obs, rows[:n], mean, std))
+            hip.mlp_weight_grad_batch(self._value_backward(vpre, g_val, obs, rows, mean, std))
+            cur.wait_stream(self.side)              # join before anything reads the gradients (all-reduce, Adam) or frees the temporaries
         return {"total_loss": metrics[0], "policy_loss": metrics[1], "v_loss": metrics[2], "entropy_loss": metrics[3]}
