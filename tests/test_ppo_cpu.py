@@ -179,3 +179,26 @@ def test_state_pytree_helpers_of_the_graph_replay():
     t = graphed.tree_map(lambda v: v + 1, s)
     assert isinstance(t, S) and t.b["n"] is None and isinstance(t.c, tuple) and torch.equal(t.b["k"][1], torch.full((2,), 2.0))
     assert torch.equal(graphed.tree_leaves(t)[0], x + 1)
+
+
+def test_actor_params_layout_of_the_in_kernel_policy():
+    """acting.actor_params: first layer as torch holds it, hidden weights transposed, head transposed and zero-padded to 64 outputs --
+    the plain-tensor evaluation of that layout reproduces the policy network."""
+    from rodent_amd.training import acting, networks, running_statistics
+    torch.manual_seed(0)
+    K, A = 57, 30
+    nets = networks.make_ppo_networks(K, A)
+    net = nets.policy_network
+    for l in net.layers:
+        l.bias.data.uniform_(-0.2, 0.2)
+    norm = running_statistics.init_state(K, torch.device("cpu"))
+    norm.mean.copy_(torch.randn(K) * 0.1); norm.std.copy_(torch.rand(K) + 0.5)
+    a = acting.actor_params(net, norm, 0.001)
+    assert a["w0"].shape == (32, K) and a["head_wt"].shape == (32, 64) and a["head_b"].shape == (64,) and len(a["hidden_wt"]) == 3
+    x = torch.randn(5, K)
+    h = torch.nn.functional.silu(((x - a["mean"]) / a["std"]) @ a["w0"].t() + a["b0"])
+    for wt, b in zip(a["hidden_wt"], a["hidden_b"]):
+        h = torch.nn.functional.silu(h @ wt + b)
+    logits = (h @ a["head_wt"] + a["head_b"])[:, :2 * A]
+    want = net((x - norm.mean) / norm.std)
+    assert torch.allclose(logits, want, atol=1e-5) and float((h @ a["head_wt"] + a["head_b"])[:, 2 * A:].abs().max()) == 0.0
