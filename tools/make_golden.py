@@ -32,6 +32,14 @@ def main():
     assert len(qpos) == 74 and len(qfrc) == 73
     json.dump({"source": "Env_step.ipynb stored outputs (cells 31 and 51)", "reset_qpos": qpos, "qfrc_actuator": qfrc},
               open(os.path.join(OUT, "env_step_reset.json"), "w"), indent=0)
+    # (2b) the WHOLE observation of that reset state, printed one value per line by the notebook (cell 8, 1260 numbers):
+    # qpos(74) | qvel(73) | cinert[1:](65 x 10) | cvel[1:](65 x 6) | qfrc_actuator(73) -- the reference's own mjx.forward output
+    obs = next(t for t in env_step if t.startswith("0.040483385\n"))
+    obs = [float(x) for x in obs.split()]
+    assert len(obs) == 1260 and obs[:3] == [0.040483385, -0.008967142, 0.075515956]
+    json.dump({"source": "Env_step.ipynb stored output of `for i in rodent_state.obs: print(i)` after reset(PRNGKey(0)); "
+                         "layout qpos(74) qvel(73) cinert[1:](650) cvel[1:](390) qfrc_actuator(73)", "obs": obs},
+              open(os.path.join(OUT, "env_step_obs.json"), "w"), indent=0)
     # (3) brax sys.link_names order and the contact struct of mjcf.ipynb
     mj = list(cell_outputs(os.path.join(REF, "mjcf.ipynb")))
     names = next(t for t in mj if t.startswith("['torso'"))
