@@ -142,11 +142,83 @@ def parse():
     return args
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N copies of this command, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment, as torch.distributed.run sets them), from a parent that never touches a GPU (no exec of a process
+    that initialised HIP; `torch.cuda.device_count()` does not initialise it on this image).  Rank 0's stdout is the JSON line."""
+    import socket
+    import subprocess
+    share = os.environ.get("RR_BENCH_SHARE_GPU") == "1"
+    have = torch.cuda.device_count()
+    if have < n and not share and os.environ.get("RR_BENCH_CPU_REHEARSAL") != "1":
+        raise SystemExit(f"bench.py --gpus {n}: {have} GPU(s) visible.  One process per GPU is the only mode measured; "
+                         "RR_BENCH_SHARE_GPU=1 rehearses the N-rank path on one GPU (gloo) and is not a scaling number.")
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        for p_ in procs:
+            rc = rc or p_.wait()
+            if rc:                                   # one rank failed: the others would wait in a collective forever
+                break
+    finally:
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.terminate()
+        for p_ in procs:
+            try:
+                p_.wait(timeout=30)
+            except Exception:
+                p_.kill()
+    return rc
+
+
+def cpu_rehearsal(args, rank, world):
+    """RR_BENCH_CPU_REHEARSAL=1 (tests/test_bench_launcher.py; NOT a measurement): the launcher, the rendezvous, ppo.train's multi-rank
+    path and the rollout / learner / all-reduce split on the CPU over gloo with a toy env -- the N-rank command shape without GPUs."""
+    import torch.distributed as dist
+    from rodent_amd.training.agents.ppo import train as ppo
+    from tests.fake_env import PointEnv
+    if world > 1:
+        dist.init_process_group("gloo")
+    times = []
+    ppo.train(environment=PointEnv(16 * world), num_timesteps=10 ** 9, episode_length=20, num_envs=16 * world, batch_size=16 * world,
+              num_minibatches=2, unroll_length=5, num_updates_per_batch=2, num_evals=2, num_eval_envs=0, normalize_observations=True, seed=0,
+              max_training_steps=args.warmup + args.steps, timing_fn=times.append)
+    timed = times[args.warmup:]
+    el = torch.tensor([sum(t["rollout_s"] + t["learner_s"] for t in timed)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "env-steps/sec (whole node), rodent 2048 envs/GPU", "value": timed[0]["env_steps"] * len(timed) / float(el), "unit": "env-steps/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "data": "cpu-rehearsal (toy env, gloo): not a measurement",
+                          "config": {"workload": "launcher rehearsal", "env_steps_per_training_step": timed[0]["env_steps"],
+                                     "rollout_s_per_training_step": sum(t["rollout_s"] for t in timed) / len(timed),
+                                     "learner_s_per_training_step": sum(t["learner_s"] for t in timed) / len(timed),
+                                     "allreduce_s_per_training_step": sum(t["allreduce_s"] for t in timed) / len(timed)}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {args.gpus}, or without a launcher)")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("RR_BENCH_CPU_REHEARSAL") == "1":
+        return cpu_rehearsal(args, rank, world)
     # rehearsal on a 1-GPU box: RR_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo (RCCL refuses two ranks
     # on one device); the driver's multi-GPU run uses one GPU per rank over RCCL
     share = os.environ.get("RR_BENCH_SHARE_GPU") == "1"
@@ -204,6 +276,8 @@ def main():
         total_env_steps = env_steps_per_step * len(timed)
         extra = {"rollout_s_per_training_step": sum(t["rollout_s"] for t in timed) / len(timed),
                  "learner_s_per_training_step": sum(t["learner_s"] for t in timed) / len(timed),
+                 # inside learner_s: the 512 gradient all-reduces + the normaliser's, as the learner's stream sees them (rank 0; 0 on one rank)
+                 "allreduce_s_per_training_step": sum(t["allreduce_s"] for t in timed) / len(timed),
                  "env_steps_per_training_step": env_steps_per_step}
         # the rollout phase's launches carry many env steps each (the whole phase is one launch when the actor runs in-kernel): the
         # roofline line is per env step of all envs = total step-kernel time / rollout steps per env (the reset launch counts ~0.1 %)

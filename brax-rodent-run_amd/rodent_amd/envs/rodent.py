@@ -8,6 +8,7 @@ substeps + reward / done / observation epilogue (C ABI `rr_env_step`).
 from __future__ import annotations
 
 import os
+import warnings
 from typing import Optional
 
 import numpy as np
@@ -43,6 +44,12 @@ class Rodent(PipelineEnv):
             raise ValueError(f"solver must be 'cg' or 'newton', got {solver!r}")
         if vision:
             raise NotImplementedError("vision observations are not part of the reference obs either")
+        if iterations < 2:
+            # measured on the float64 oracle as on the GPU: with ONE solver iteration per substep the rollout under
+            # random actions reaches |qvel| > 1e4 and non-finite states within two env steps (Newton 1/4), within a few (CG 1/4)
+            warnings.warn(f"Rodent(solver={solver!r}, iterations={iterations}): a single solver iteration per substep diverges "
+                          "under random actions (non-finite states within a few env steps, on the CPU oracle too); use iterations >= 2",
+                          RuntimeWarning, stacklevel=2)
         sys = System(assets.resolve_model(xml_path), iterations, ls_iterations, solver)
         physics_steps_per_control_step = 10   # [REF Rodent_Env_Brax.py:53-57]
         kwargs["n_frames"] = kwargs.get("n_frames", physics_steps_per_control_step)

@@ -146,7 +146,7 @@ def train(
     normalize = running_statistics.normalize if normalize_observations else (lambda x, y: x)
     make_policy = ppo_networks_mod.make_inference_fn(ppo_network)
     training_state = TrainingState(optimizer_state=optimizer, params=PPONetworkParams(policy=policy_net, value=value_net),
-                                   normalizer_params=normalizer_params, env_steps=torch.zeros((), dtype=torch.int32))
+                                   normalizer_params=normalizer_params, env_steps=torch.zeros((), dtype=torch.int64))
 
     def current_params():
         return (normalizer_params if normalize_observations else None, policy_net)
@@ -265,6 +265,8 @@ def train(
             gstate["graph_b"].replay()
         return gstate["metrics"]
 
+    D.time_collectives(timing_fn is not None)
+
     def training_step():
         nonlocal env_state, normalizer_params
         t0 = time.time()
@@ -306,9 +308,12 @@ def train(
         sync()
         t2 = time.time()
         training_state.normalizer_params = normalizer_params
-        training_state.env_steps += env_step_per_training_step          # int32, as upstream
+        training_state.env_steps += env_step_per_training_step          # int64 (upstream: int32, which wraps past 2.1e9 steps)
         if timing_fn is not None:
-            timing_fn({"rollout_s": t1 - t0, "learner_s": t2 - t1, "env_steps": env_step_per_training_step})
+            # allreduce_s: the part of learner_s spent in the gradient / normaliser all-reduces as the learner's stream sees them
+            # (0 on one rank); SURVEY.md 8(d): rollout / learner / all-reduce
+            timing_fn({"rollout_s": t1 - t0, "learner_s": t2 - t1, "allreduce_s": D.pop_collective_seconds(),
+                       "env_steps": env_step_per_training_step})
         return {f"training/{k}": float(v) for k, v in metrics.items()}
 
     metrics = {}

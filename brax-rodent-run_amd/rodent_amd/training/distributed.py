@@ -15,16 +15,52 @@ def rank() -> int:
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+# Time spent in the collectives (config 3 / 4 report rollout / learner / all-reduce).  On a GPU the all-reduce is
+# bracketed by events on the CURRENT stream -- torch issues the RCCL kernel on its own stream and makes the current stream wait for
+# it, so the pair spans the collective as the learner's stream sees it (incl. waiting for the slowest rank); on the CPU, wall time.
+_TIMER = {"on": False, "events": [], "wall": 0.0}
+
+
+def time_collectives(enable: bool):
+    _TIMER["on"] = bool(enable)
+    _TIMER["events"].clear()
+    _TIMER["wall"] = 0.0
+
+
+def pop_collective_seconds() -> float:
+    """Seconds inside all-reduces since the last call (the caller has synchronised the device)."""
+    s = _TIMER["wall"] + sum(e0.elapsed_time(e1) for e0, e1 in _TIMER["events"]) * 1e-3
+    _TIMER["events"].clear()
+    _TIMER["wall"] = 0.0
+    return s
+
+
+def _all_reduce(t: torch.Tensor):
+    if not _TIMER["on"]:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    elif t.is_cuda and not torch.cuda.is_current_stream_capturing():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        e1.record()
+        _TIMER["events"].append((e0, e1))
+    else:
+        import time
+        t0 = time.perf_counter()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        _TIMER["wall"] += time.perf_counter() - t0
+
+
 def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
     if world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        _all_reduce(t)
     return t
 
 
 def all_reduce_mean_(t: torch.Tensor) -> torch.Tensor:
     """`jax.lax.pmean(x, 'i')`."""
     if world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        _all_reduce(t)
         t.div_(world_size())
     return t
 

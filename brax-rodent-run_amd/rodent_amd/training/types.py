@@ -19,4 +19,4 @@ class TrainingState:
     optimizer_state: Any             # torch.optim.Adam (optax.adam(lr): b1 .9, b2 .999, eps 1e-8)
     params: PPONetworkParams
     normalizer_params: Any           # running_statistics.RunningStatisticsState
-    env_steps: torch.Tensor          # int32 scalar, += env_steps_per_training_step per training step (as upstream)
+    env_steps: torch.Tensor          # int64 scalar, += env_steps_per_training_step per training step (upstream: int32)

@@ -181,3 +181,30 @@ def test_float32_divergence_is_inherent(oracle_built):
     assert gap[0] < 2e-3                     # one env-step (10 substeps): round-off, already amplified by joint limits
     assert np.all(np.isfinite(res["f32"]))
     assert gap[-1] > 1e-5                    # contact dynamics amplify it well past 1e-5 within 60 env-steps
+
+
+def test_one_newton_iteration_diverges_on_the_oracle_too(oracle_built):
+    """Round 2's record gpurun_out/nb_a_newton_1_4.err: `bench.py --solver newton --iterations 1 --ls-iterations 4` ended in
+    "non-finite state in the rollout" on the GPU.  The same rollout (bench.py's reset keys, fresh U(-1,1) actions, Episode(150) +
+    AutoReset) on the float64 ORACLE: within two env steps joint velocities pass 1e4 rad/s and states go non-finite -- one Newton step
+    with a 4-iteration line search leaves an iterate that the next substeps amplify; it is the configuration that diverges, not the
+    kernel's Hessian factorisation.  Newton 4/8 from the same states stays bounded.  `Rodent(iterations < 2)` warns (envs/rodent.py)."""
+    from rodent_amd import jax_random as jr
+    from tests import util
+    from tests.oracle_env import OracleRodent
+    N = 128
+    keys = jr.split(jr.fold_in(jr.PRNGKey(0), 0), N)
+    worst = {}
+    for it in ((1, 4), (4, 8)):
+        E = OracleRodent("rodent_optimized", N, "f64", it, util.synthetic_track(), episode_length=150)
+        E.M.set_solver("newton")
+        E.reset(keys)
+        rng = np.random.default_rng(1234)
+        w = 0.0
+        for t in range(3):
+            E.step(rng.uniform(-1, 1, (N, 30)))
+            v = E.state()["qvel"]
+            w = max(w, float(np.abs(np.where(np.isfinite(v), v, np.inf)).max()))
+        worst[it] = w
+    print("max |qvel| over 3 env steps of %d envs, float64 oracle:" % N, worst)
+    assert worst[(1, 4)] > 1e4 and worst[(4, 8)] < 2e3

@@ -89,6 +89,25 @@ def test_teacher_forced_env_steps_newton(oracle_built):
     parity.check_quantiles(out["quantiles"], parity.ENV_FLOORS)
 
 
+def test_teacher_forced_substeps_short_solver_settings(oracle_built):
+    """The notebook's setting CG 2/4 [NB /root/reference/mjcf.ipynb:444] and Newton 1/4 -- the setting whose FREE-RUNNING rollout went
+    non-finite on the GPU in round 2 (gpurun_out/nb_a_newton_1_4.err).  The oracle diverges in the same way (float64 and float32:
+    tests/test_abi_and_oracle.py::test_one_newton_iteration_diverges_on_the_oracle_too), so it is the configuration, not the kernel;
+    what CAN be held is the one-step map, started from states of a stable trajectory (Newton 4/8 / CG 8/8)."""
+    N = 16
+    seq, _, tab = parity.rollout_inputs("rodent_optimized", N, 150, (4, 8), seed=51, solver="newton")
+    A = parity.OracleImpl("rodent_optimized", N, "f64", (1, 4), "newton")
+    out = parity.substep_ladder(HipImpl("rodent_optimized", N, (1, 4), True, solver="newton"), seq, A,
+                                parity.OracleImpl("rodent_optimized", N, "f32", (1, 4), solver="newton"))
+    _report("substeps_newton_1_4", out)
+    parity.assert_substep_criteria(out, newton=True)
+    seq, _, tab = parity.rollout_inputs("rodent_optimized", N, 300, (8, 8), seed=53)
+    A = parity.OracleImpl("rodent_optimized", N, "f64", (2, 4))
+    out = parity.substep_ladder(HipImpl("rodent_optimized", N, (2, 4), True), seq, A, parity.OracleImpl("rodent_optimized", N, "f32", (2, 4)))
+    _report("substeps_cg_2_4", out)
+    parity.assert_substep_criteria(out)
+
+
 def test_newton_is_refused_for_models_without_an_instance():
     from rodent_amd import assets, hip
     with pytest.raises(RuntimeError, match="Newton"):

@@ -155,7 +155,7 @@ def test_training_state_is_carried():
                     num_minibatches=2, unroll_length=5, num_updates_per_batch=2, num_evals=1, num_eval_envs=0,
                     normalize_observations=True, seed=1, return_training_state=True)
     ts = out[3]
-    assert ts.env_steps.dtype == torch.int32 and int(ts.env_steps) == 16 * 5 * 2 * 3
+    assert ts.env_steps.dtype == torch.int64 and int(ts.env_steps) == 16 * 5 * 2 * 3
     assert float(ts.normalizer_params.count) == 16 * 5 * 2 * 3
     assert ts.params.policy is out[1][1] and len(ts.optimizer_state.state) > 0
 
