@@ -5,6 +5,7 @@
 #include "rr_mlp.h"
 #include "rr_ppo.h"
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -36,6 +37,7 @@ struct rr_model {
   int NBS, NVS, NCS;
   bool stage_ok = true;
   int solver = 1;          // 1 = CG, 2 = Newton [REF Rodent_Env_Brax.py:42-45]
+  mutable std::atomic<int> live_batches{0};     // batches bake the model's LDS layout at creation: the solver type is fixed while any exist
 
   const Entry* find(const char* n) const { auto it = e.find(n); return it == e.end() ? nullptr : &it->second; }
   int iscalar(const char* n) const { const Entry* x = find(n); return x ? ((const int32_t*)x->data)[0] : 0; }
@@ -161,6 +163,8 @@ extern "C" int rr_model_set_solver(rr_model* m, int32_t it, int32_t ls) {
 }
 extern "C" int rr_model_set_solver_type(rr_model* m, int32_t solver) {
   if (!m || (solver != 1 && solver != 2)) return fail(RR_EINVAL, "rr_model_set_solver_type: solver must be 1 (cg) or 2 (newton)");
+  if (solver != m->solver && m->live_batches.load() > 0)
+    return fail(RR_EINVAL, "rr_model_set_solver_type: batches of this model exist (they hold the LDS layout of the current solver); set the solver before rr_batch_create");
   if (solver == 2 && !(m->NBS == 2 && m->NVS == 2 && m->NCS == 1))
     return fail(RR_EUNSUPPORTED, "rr_model_set_solver_type: the Newton instance exists for the single-rodent models only");
   if (solver == 2 && 4 * ((m->dims.nv + 3) & ~3) > std::max(7 * m->dims.nbody + 4, 6 * m->dims.nv))
@@ -202,6 +206,7 @@ struct rr_batch {
   unsigned long long* prof = nullptr;   // diagnostic phase-cycle buffer (rr_batch_set_profile)
   const int32_t* env_map = nullptr;     // rr_batch_set_schedule
   uint32_t* cost = nullptr;
+  bool counted = false;                 // this batch is in m->live_batches
 };
 
 template <typename Ptr>
@@ -296,16 +301,25 @@ extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t devi
   kern_t kern = pick_kernel(m);
   if (!m->stage_ok) { rr_batch_destroy(b); return fail(RR_EUNSUPPORTED, "rr_batch_create: 4*ncon + nv exceeds the line-search staging cells (6*nbody)"); }
   if (m->dims.lds_bytes > 64 * 1024) { rr_batch_destroy(b); return fail(RR_EUNSUPPORTED, "rr_batch_create: per-env working set exceeds the 64 KiB of LDS one workgroup may address"); }
-  for (kern_t kk : {kern, pick_kernel(m, false, true)}) {   // production and debug-dump instances
+  for (kern_t kk : {kern, pick_kernel(m, false, true), pick_unroll_kernel(m), pick_unroll_kernel(m, true), pick_kernel(m, true)}) {   // every instance a launch may pick
+    if (!kk) continue;
     hipError_t e = hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, m->dims.lds_bytes);
     if (e != hipSuccess) { rr_batch_destroy(b); return fail(RR_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
+    // the level schedules address LDS by absolute byte address, so the dynamic segment must begin at LDS address 0: no static LDS
+    hipFuncAttributes fa;
+    e = hipFuncGetAttributes(&fa, (const void*)kk);
+    if (e != hipSuccess) { rr_batch_destroy(b); return fail(RR_EHIP, std::string("hipFuncGetAttributes: ") + hipGetErrorString(e)); }
+    if (fa.sharedSizeBytes != 0) { rr_batch_destroy(b); return fail(RR_EUNSUPPORTED, "rr_batch_create: a step-kernel instance has static LDS (the level schedules need the dynamic segment at address 0)"); }
   }
+  m->live_batches.fetch_add(1);
+  b->counted = true;
   *out = b;
   return RR_OK;
 }
 
 extern "C" void rr_batch_destroy(rr_batch* b) {
   if (!b) return;
+  if (b->counted) b->m->live_batches.fetch_sub(1);
   for (void* p : b->dev_allocs) (void)hipFree(p);
   for (hipEvent_t e : b->ev0) (void)hipEventDestroy(e);
   for (hipEvent_t e : b->ev1) (void)hipEventDestroy(e);

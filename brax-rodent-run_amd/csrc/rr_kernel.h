@@ -1917,8 +1917,8 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int env = blockIdx.x;
   if (env >= num_envs) return;
-  // the level schedules address LDS by absolute byte address: the dynamic segment must start at 0 (no static LDS here)
-  if ((unsigned)(size_t)(float __attribute__((address_space(3)))*)lds != 0u) __builtin_trap();
+  // the level schedules address LDS by absolute byte address: the dynamic segment must start at 0, i.e. the kernel has no static
+  // LDS -- checked on the HOST for every instance a batch may launch (rr_batch_create: hipFuncGetAttributes().sharedSizeBytes == 0)
   const DT D(Dk);
   Wave<NBS, NVS, NCS, DT, NEWTON> w(D, T, lds);
   int lane = threadIdx.x;
@@ -1957,7 +1957,13 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
     if (ut == 0) {       // the observation the rollout starts from is row 0 of the env's trajectory
       for (int i = lane; i < D.obs_dim; i += RR_LANES) io.t_obs[rr_traj_obs(io, num_envs, env, 0, 0) * D.obs_dim + i] = io.a_obs_in[(size_t)env * D.obs_dim + i];
     }
+    // ORDERING through global memory inside one wave: the observation row the actor reads was written by OTHER lanes of this wave (the
+    // previous step's epilogue / the copy above), and the action it writes (lanes < A) is read back as ctrl by all lanes below.  Same-wave
+    // vector memory operations complete in order, but the compiler must not move them across each other either: a wavefront-scope fence on
+    // both sides states the dependency (guarded by tests/test_gpu_ppo.py::test_one_launch_unroll_with_the_actor_inside, bitwise).
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     rr_actor_step(io, D, lane, env, ut, num_envs);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
   // ---- load state (a multi-step rollout keeps it in LDS after its first step)
   if (!UNROLL || ut == 0) {
