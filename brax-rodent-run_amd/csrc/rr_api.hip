@@ -23,6 +23,7 @@ extern "C" const char* rr_last_error(void) { return g_err.c_str(); }
     if (e_ != hipSuccess) return fail(RR_EHIP, std::string(#x) + ": " + hipGetErrorString(e_));   \
   } while (0)
 
+typedef void (*kern_t)(const RRDims, const RRTables, const RRIO, const int, const int);
 // ------------------------------------------------------------------------------------------ model
 struct Entry { int dtype, ndim, dims[4]; size_t count; const void* data; };
 
@@ -37,6 +38,10 @@ struct rr_model {
   int NBS, NVS, NCS;
   bool stage_ok = true;
   int solver = 1;          // 1 = CG, 2 = Newton [REF Rodent_Env_Brax.py:42-45]
+  // two identical trees (rodent_pair.xml): dims / LDS layout of ONE replica for the two-wave instance (rr_kernel.h PAIR), from the
+  // blob's h_* tables; pair_ok = the blob carries them and a PAIR kernel instance matches
+  bool pair_ok = false;
+  RRDims kd_rep;
   mutable std::atomic<int> live_batches{0};     // batches bake the model's LDS layout at creation: the solver type is fixed while any exist
 
   const Entry* find(const char* n) const { auto it = e.find(n); return it == e.end() ? nullptr : &it->second; }
@@ -74,6 +79,45 @@ static void layout(rr_model* m) {
   m->dims.lds_bytes = o * (int)sizeof(float);
   m->dims.dbg_floats = g;
   m->dims.solver = m->solver;
+}
+
+static kern_t pick_pair_kernel(const rr_model* m);
+// Two-wave (PAIR) instance: dims of one replica from the blob's h_* tables (rodent_amd/ktables.py replica_model).  RR_PAIR_WAVES=0
+// keeps such models on the generic one-wave instance (A/B runs).
+static void setup_replica(rr_model* m) {
+  m->pair_ok = false;
+  const char* sw = getenv("RR_PAIR_WAVES");
+  if (sw && sw[0] == '0') return;
+  static const char* need[] = {"h_dims", "h_k_slots", "h_k_body_i", "h_k_body_f", "h_k_jnt_i", "h_k_jnt_f", "h_k_dof_i", "h_k_dof_f", "h_k_act_f", "h_k_M_ij_k",
+                               "h_k_body_anc", "h_k_nround", "h_k_factor3", "h_k_factor3_rows", "h_k_linv", "h_k_linv_rows", "h_k_coljob", "h_k_rowjob", "h_k_jobown",
+                               "h_k_solve_lmax", "h_k_solve_cmax", "h_k_solve_rmax", "h_k_con_i", "h_k_con_f", "h_k_con_chain_rows", "h_k_root_mass"};
+  for (const char* n : need) if (!m->find(n)) return;
+  const int32_t* hd = (const int32_t*)m->find("h_dims")->data;       // nq nv nu nbody njnt nM ncon dmax
+  const int32_t* sl = (const int32_t*)m->find("h_k_slots")->data;
+  if (m->find("h_dims")->count < 8 || sl[0] != 2 || sl[1] != 2 || sl[2] != 1) return;
+  if (2 * hd[0] != m->dims.nq || 2 * hd[1] != m->dims.nv || 2 * hd[2] != m->dims.nu || 2 * hd[6] != m->dims.ncon || m->dims.na != m->dims.nu) return;
+  RRDims k = m->kd;          // options, gravity, tolerances, meaninertia: the model's
+  k.nq = hd[0]; k.nv = hd[1]; k.nu = hd[2]; k.nbody = hd[3]; k.njnt = hd[4]; k.nM = hd[5]; k.ncon = hd[6]; k.dmax = hd[7];
+  k.nroot = (int)m->find("h_k_root_mass")->count;
+  k.nround = m->iscalar("h_k_nround"); k.ninv = m->iscalar("h_k_linv_rows"); k.nfac = m->iscalar("h_k_factor3_rows");
+  k.lmax = m->iscalar("h_k_solve_lmax"); k.cmax = m->iscalar("h_k_solve_cmax"); k.rmax = m->iscalar("h_k_solve_rmax");
+  k.obs_dim = k.nq + k.nv + 16 * (k.nbody - 1) + k.nv + 3;
+  const RRLayout L = rr_layout(k.nq, k.nv, k.nu, k.nbody, k.nM, k.ncon, false);
+  k.o_qpos = L.o_qpos; k.o_qvel = L.o_qvel; k.o_act = L.o_act; k.o_ctrl = L.o_ctrl; k.o_xpos = L.o_xpos; k.o_xquat = L.o_xquat;
+  k.o_cinert = L.o_cinert; k.o_cdof = L.o_cdof; k.o_cvel = L.o_cvel; k.o_qLD = L.o_qLD; k.o_vec = L.o_vec; k.o_x = L.o_x;
+  k.o_arm = L.o_arm; k.o_warm = L.o_warm; k.o_qact = L.o_qact; k.o_jlist = L.o_jlist; k.lds_floats = L.lds_floats;
+  k.o_H = k.o_Mp = k.o_anc = 0; k.solver = 1;
+  k.nv_scale = m->dims.nv;                          // the solver's tolerances scale with the MODEL's dof count
+  k.lds_bytes_rep = L.lds_floats * 4;
+  k.fac_stride = (int)m->find("h_k_factor3")->count; k.inv_stride = (int)m->find("h_k_linv")->count;
+  const int njs = 2 * RR_LANES;
+  if ((int)m->find("h_k_coljob")->count != 9 * njs || (int)m->find("h_k_rowjob")->count != 5 * njs || k.lmax > 16 || k.lmax < 1 || k.cmax > 8 || k.rmax > 8 || k.cmax < 1) return;
+  if (k.nM > RR_LANES * 18 || k.nroot != 1) return;
+  const bool stage_ok = 2 * (k.nbody + 8) <= std::max(7 * k.nbody + 4, 6 * k.nv) && 6 * k.ncon <= std::max(7 * k.nbody + 4, 6 * k.nv) &&
+                        4 * k.ncon + k.nv <= std::min(std::min(10 * k.nbody, 6 * k.nbody), std::max(7 * k.nbody + 4, 6 * k.nv));
+  if (!stage_ok || 2 * k.lds_bytes_rep + 128 > 64 * 1024) return;
+  m->kd_rep = k;
+  m->pair_ok = pick_pair_kernel(m) != nullptr;
 }
 
 extern "C" int rr_model_load(const char* path, rr_model** out) {
@@ -145,7 +189,9 @@ extern "C" int rr_model_load(const char* path, rr_model** out) {
   if (m->find("k_body_i")->dims[1] != RR_BODYI) { delete m; return fail(RR_EIO, "rr_model_load: k_body_i width mismatch (stale blob)"); }
   if (d.nv > 256 || d.ncon > 256) { delete m; return fail(RR_EUNSUPPORTED, "rr_model_load: nv/ncon above the 8-bit table index"); }
   if (m->find("k_con_chain_packed")->dims[1] != m->NCS * RR_LANES) { delete m; return fail(RR_EIO, "rr_model_load: lane-table width mismatch"); }
+  k.nv_scale = d.nv > 1 ? d.nv : 1;
   layout(m);
+  setup_replica(m);
   *out = m;
   return RR_OK;
 }
@@ -197,6 +243,7 @@ struct rr_batch {
   hipStream_t stream;
   RRDims kd;
   RRTables T;
+  RRTables T_rep;                       // tables of one replica (two-wave instance of a two-tree model; m->pair_ok)
   std::vector<void*> dev_allocs;
   bool timing = false;
   std::vector<hipEvent_t> ev0, ev1;     // ring of event pairs: launches are timed without a host sync per launch
@@ -221,17 +268,23 @@ static int upload(rr_batch* b, const char* name, Ptr* dst) {
   return RR_OK;
 }
 
-// Level schedules (k_factor3, k_linv): element indices -> LDS byte addresses of the sparse-matrix array (rr_kernel.h run_levels)
-static int upload_levels(rr_batch* b, const char* name, rr_gi* dst) {
+// Level schedules (k_factor3, k_linv): element indices -> LDS byte addresses of the sparse-matrix array (rr_kernel.h run_levels).
+// `copies` = 2 (two-wave instance): a second copy behind the first, addressed into the second wavefront's LDS region (+ rep_bytes).
+static int upload_levels(rr_batch* b, const char* name, rr_gi* dst, uint32_t base = ~0u, int copies = 1, uint32_t rep_bytes = 0) {
   const Entry* e = b->m->find(name);
-  const uint32_t base = (uint32_t)b->m->kd.o_qLD * 4u;
-  std::vector<uint32_t> t((const uint32_t*)e->data, (const uint32_t*)e->data + e->count);
-  for (size_t i = 0; i + 3 < t.size(); i += 4) {        // x = a | b0 << 16, y = d0 | d1 << 16, z = d2 | d3 << 16, w = q | flags << 8
-    uint32_t f[6] = {t[i] & 0xFFFFu, t[i] >> 16, t[i + 1] & 0xFFFFu, t[i + 1] >> 16, t[i + 2] & 0xFFFFu, t[i + 2] >> 16};
-    for (uint32_t& v : f) { v = v * 8u + base; if (v > 0xFFFFu) return fail(RR_EUNSUPPORTED, "level schedule does not fit the 16-bit LDS address fields"); }   // 8 bytes per entry: pairs
-    const uint32_t q = (t[i + 3] & 0xFFu) * 8u, flags = t[i + 3] >> 8;
-    t[i] = f[0] | (f[1] << 16); t[i + 1] = f[2] | (f[3] << 16); t[i + 2] = f[4] | (f[5] << 16);
-    t[i + 3] = q | (flags << 16);
+  if (base == ~0u) base = (uint32_t)b->m->kd.o_qLD * 4u;
+  std::vector<uint32_t> t((size_t)copies * e->count);
+  for (int c = 0; c < copies; ++c) {
+    const uint32_t* src = (const uint32_t*)e->data;
+    uint32_t* tc = t.data() + (size_t)c * e->count;
+    const uint32_t cb = base + (uint32_t)c * rep_bytes;
+    for (size_t i = 0; i + 3 < e->count; i += 4) {        // x = a | b0 << 16, y = d0 | d1 << 16, z = d2 | d3 << 16, w = q | flags << 8
+      uint32_t f[6] = {src[i] & 0xFFFFu, src[i] >> 16, src[i + 1] & 0xFFFFu, src[i + 1] >> 16, src[i + 2] & 0xFFFFu, src[i + 2] >> 16};
+      for (uint32_t& v : f) { v = v * 8u + cb; if (v > 0xFFFFu) return fail(RR_EUNSUPPORTED, "level schedule does not fit the 16-bit LDS address fields"); }   // 8 bytes per entry: pairs
+      const uint32_t q = (src[i + 3] & 0xFFu) * 8u, flags = src[i + 3] >> 8;
+      tc[i] = f[0] | (f[1] << 16); tc[i + 1] = f[2] | (f[3] << 16); tc[i + 2] = f[4] | (f[5] << 16);
+      tc[i + 3] = q | (flags << 16);
+    }
   }
   void* p = nullptr;
   HIPCHK(hipMalloc(&p, t.size() * 4));
@@ -241,7 +294,6 @@ static int upload_levels(rr_batch* b, const char* name, rr_gi* dst) {
   return RR_OK;
 }
 
-typedef void (*kern_t)(const RRDims, const RRTables, const RRIO, const int, const int);
 // Instances: production (no debug dump; fixed-dimension variant for the rodent dims), debug dump (generic dims; selected per
 // launch when rr_outputs.debug is given), cycle-stamp profile (diagnostic, rodent dims or generic 2,2,1).
 static kern_t pick_kernel(const rr_model* m, bool prof = false, bool dbg = false) {
@@ -255,7 +307,8 @@ static kern_t pick_kernel(const rr_model* m, bool prof = false, bool dbg = false
     if (nbs == 3 && nvs == 3 && ncs == 2) return rr_step_kernel<3, 3, 2, false, true, RRDims>;
     return nullptr;
   }
-  if (nbs == 2 && nvs == 2 && ncs == 1 && RRDimsRodent::matches(m->kd)) return rr_step_kernel<2, 2, 1, false, false, RRDimsRodent>;   // fixed-dimension instance
+  if (nbs == 2 && nvs == 2 && ncs == 1 && RRDimsRodent::matches(m->kd)) return rr_step_kernel<2, 2, 1, false, false, RRDimsRodent>;   // fixed-dimension instances
+  if (nbs == 2 && nvs == 2 && ncs == 1 && RRDimsRodentNew::matches(m->kd)) return rr_step_kernel<2, 2, 1, false, false, RRDimsRodentNew>;
   if (nbs == 1 && nvs == 1 && ncs == 1) return rr_step_kernel<1, 1, 1, false, false, RRDims>;
   if (nbs == 2 && nvs == 2 && ncs == 1) return rr_step_kernel<2, 2, 1, false, false, RRDims>;
   if (nbs == 3 && nvs == 3 && ncs == 2) return rr_step_kernel<3, 3, 2, false, false, RRDims>;
@@ -264,8 +317,15 @@ static kern_t pick_kernel(const rr_model* m, bool prof = false, bool dbg = false
 
 static kern_t pick_unroll_kernel(const rr_model* m, bool actor = false) {
   if (m->solver == 2 || !(m->NBS == 2 && m->NVS == 2 && m->NCS == 1)) return nullptr;
-  if (actor) return RRDimsRodent::matches(m->kd) ? rr_step_kernel<2, 2, 1, false, false, RRDimsRodent, false, true, true> : rr_step_kernel<2, 2, 1, false, false, RRDims, false, true, true>;
-  return RRDimsRodent::matches(m->kd) ? rr_step_kernel<2, 2, 1, false, false, RRDimsRodent, false, true> : rr_step_kernel<2, 2, 1, false, false, RRDims, false, true>;
+  if (actor) return RRDimsRodent::matches(m->kd) ? rr_step_kernel<2, 2, 1, false, false, RRDimsRodent, false, true, true>
+                    : (RRDimsRodentNew::matches(m->kd) ? rr_step_kernel<2, 2, 1, false, false, RRDimsRodentNew, false, true, true> : rr_step_kernel<2, 2, 1, false, false, RRDims, false, true, true>);
+  return RRDimsRodent::matches(m->kd) ? rr_step_kernel<2, 2, 1, false, false, RRDimsRodent, false, true>
+         : (RRDimsRodentNew::matches(m->kd) ? rr_step_kernel<2, 2, 1, false, false, RRDimsRodentNew, false, true> : rr_step_kernel<2, 2, 1, false, false, RRDims, false, true>);
+}
+// the two-wave instance of a two-tree model (one replica = the rodent_new dims); nullptr: no such instance -> generic one-wave kernel
+static kern_t pick_pair_kernel(const rr_model* m) {
+  if (m->solver == 2) return nullptr;
+  return RRDimsRodentNew::matches(m->kd_rep) ? rr_step_kernel<2, 2, 1, false, false, RRDimsRodentNew, false, false, false, true> : nullptr;
 }
 
 extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t device, void* stream, rr_batch** out) {
@@ -282,6 +342,18 @@ extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t devi
   UP(act_f, "k_act_f") UP(con_f, "k_con_f") UP(root_mass, "k_root_mass")
 #undef UP
   if ((rc = upload_levels(b, "k_factor3", &b->T.factor3)) || (rc = upload_levels(b, "k_linv", &b->T.linv))) { rr_batch_destroy(b); return rc; }
+  memset(&b->T_rep, 0, sizeof(b->T_rep));
+  if (m->pair_ok) {      // tables of one replica; the level schedules twice (second copy addressed into the second wavefront's region)
+#define UPH(field, name) if ((rc = upload(b, "h_" name, &b->T_rep.field))) { rr_batch_destroy(b); return rc; }
+    UPH(body_i, "k_body_i") UPH(jnt_i, "k_jnt_i") UPH(dof_i, "k_dof_i") UPH(M_ij_k, "k_M_ij_k")
+    UPH(body_anc, "k_body_anc") UPH(con_chain_rows, "k_con_chain_rows") UPH(coljob, "k_coljob") UPH(rowjob, "k_rowjob") UPH(jobown, "k_jobown") UPH(con_i, "k_con_i")
+    UPH(body_f, "k_body_f") UPH(jnt_f, "k_jnt_f") UPH(dof_f, "k_dof_f")
+    UPH(act_f, "k_act_f") UPH(con_f, "k_con_f") UPH(root_mass, "k_root_mass")
+#undef UPH
+    const uint32_t base = (uint32_t)m->kd_rep.o_qLD * 4u, rb = (uint32_t)m->kd_rep.lds_bytes_rep;
+    if ((rc = upload_levels(b, "h_k_factor3", &b->T_rep.factor3, base, 2, rb)) || (rc = upload_levels(b, "h_k_linv", &b->T_rep.linv, base, 2, rb))) { rr_batch_destroy(b); return rc; }
+    b->T_rep.anc4 = b->T_rep.M_ij_k;     // unused (Newton only); a valid pointer
+  }
   {   // ancestor ids along the rows of M (Newton): byte Madr[i] + p = the p-th ancestor of dof i (p = 0: i itself)
     const Entry *an = m->find("dof_anc"), *ad = m->find("dof_ancadr"), *ma = m->find("dof_Madr");
     std::vector<unsigned char> bytes(((size_t)m->dims.nM + 3) / 4 * 4 + 4, 0);
@@ -301,9 +373,10 @@ extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t devi
   kern_t kern = pick_kernel(m);
   if (!m->stage_ok) { rr_batch_destroy(b); return fail(RR_EUNSUPPORTED, "rr_batch_create: 4*ncon + nv exceeds the line-search staging cells (6*nbody)"); }
   if (m->dims.lds_bytes > 64 * 1024) { rr_batch_destroy(b); return fail(RR_EUNSUPPORTED, "rr_batch_create: per-env working set exceeds the 64 KiB of LDS one workgroup may address"); }
-  for (kern_t kk : {kern, pick_kernel(m, false, true), pick_unroll_kernel(m), pick_unroll_kernel(m, true), pick_kernel(m, true)}) {   // every instance a launch may pick
+  kern_t pair_kern = m->pair_ok ? pick_pair_kernel(m) : nullptr;
+  for (kern_t kk : {kern, pick_kernel(m, false, true), pick_unroll_kernel(m), pick_unroll_kernel(m, true), pick_kernel(m, true), pair_kern}) {   // every instance a launch may pick
     if (!kk) continue;
-    hipError_t e = hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, m->dims.lds_bytes);
+    hipError_t e = hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, kk == pair_kern ? 2 * m->kd_rep.lds_bytes_rep + 128 : m->dims.lds_bytes);
     if (e != hipSuccess) { rr_batch_destroy(b); return fail(RR_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
     // the level schedules address LDS by absolute byte address, so the dynamic segment must begin at LDS address 0: no static LDS
     hipFuncAttributes fa;
@@ -402,11 +475,19 @@ static int launch(rr_batch* b, const rr_state* st, const float* ctrl, int n_fram
   io.env_map = b->env_map; io.cost = b->cost;
   RRDims kd = b->kd;
   kd.iterations = b->m->kd.iterations; kd.ls_iterations = b->m->kd.ls_iterations;
+  // two-tree model, physics only, no diagnostics: one wavefront per replica (rr_kernel.h PAIR)
+  const bool pair = b->m->pair_ok && !env && !out && !un && !b->prof && !b->env_map && !b->cost && b->m->solver != 2;
+  if (pair) {
+    kern = pick_pair_kernel(b->m);
+    kd = b->m->kd_rep;
+    kd.iterations = b->m->kd.iterations; kd.ls_iterations = b->m->kd.ls_iterations;
+  }
   if (b->timing) {
     if (b->npending == RR_TIMING_RING) { int rc = collect_timing(b, false); if (rc) return rc; }
     HIPCHK(hipEventRecord(b->ev0[(b->ring_head + b->npending) % RR_TIMING_RING], b->stream));
   }
-  hipLaunchKernelGGL(kern, dim3(b->N), dim3(RR_LANES), (size_t)b->m->dims.lds_bytes, b->stream, kd, b->T, io, b->N, n_frames);
+  if (pair) hipLaunchKernelGGL(kern, dim3(b->N), dim3(2 * RR_LANES), (size_t)(2 * kd.lds_bytes_rep + 128), b->stream, kd, b->T_rep, io, b->N, n_frames);
+  else hipLaunchKernelGGL(kern, dim3(b->N), dim3(RR_LANES), (size_t)b->m->dims.lds_bytes, b->stream, kd, b->T, io, b->N, n_frames);
   HIPCHK(hipGetLastError());
   if (b->timing) {
     HIPCHK(hipEventRecord(b->ev1[(b->ring_head + b->npending) % RR_TIMING_RING], b->stream));

@@ -45,6 +45,10 @@ struct RRDims {
       o_qLD, o_vec, o_x, o_arm, o_warm, o_qact, o_jlist, lds_floats;
   // Newton instance only (solver == 2): pair arrays of the Hessian and of a copy of M, ancestor-id bytes; 0 otherwise
   int o_H, o_Mp, o_anc, solver;
+  // nv_scale: the dof count the solver's tolerances are scaled by (= nv; a PAIR instance runs one replica of nv dofs per wavefront of a
+  // 2 nv-dof model).  fac_stride / inv_stride (ints): PAIR instances hold a second copy of each level schedule behind the first, its
+  // LDS addresses moved to the second wavefront's region.  lds_bytes_rep: LDS bytes of one replica's region
+  int nv_scale, fac_stride, inv_stride, lds_bytes_rep;
   // debug dump offsets (floats)
   int g_xpos, g_xquat, g_xmat, g_com, g_cinert, g_crb, g_cdof, g_cvel, g_cfrc, g_qM, g_qLD, g_dinv, g_bias, g_passive,
       g_actuator, g_smooth, g_qacc_smooth, g_con_dist, g_con_pos, g_con_frame, g_con_D, g_con_aref, g_lim, g_qacc,
@@ -96,14 +100,15 @@ constexpr RRLayout rr_layout(int nq, int nv, int nu, int nbody, int nM, int ncon
 // has its loop bounds, bounds checks and LDS addresses as immediates instead of ~40 scalar registers (the generic instance
 // spills hundreds of SGPRs to VGPR lanes).  Members of the same name hide the run-time fields of RRDims; everything else
 // (solver options, table row counts, debug offsets) stays run-time.  The host selects it only when every constant matches.
-struct RRDimsRodent : RRDims {
-  static constexpr int nq = 74, nv = 73, nu = 30, nbody = 66, njnt = 68, nM = 1119, ncon = 59, dmax = 35, nroot = 1, obs_dim = 1263, nround = 6, lmax = 12, cmax = 6, rmax = 3;
+template <int NBODY_, int NCON_, int OBS_>
+struct RRDimsFixed : RRDims {
+  static constexpr int nq = 74, nv = 73, nu = 30, nbody = NBODY_, njnt = 68, nM = 1119, ncon = NCON_, dmax = 35, nroot = 1, obs_dim = OBS_, nround = 6, lmax = 12, cmax = 6, rmax = 3;
   static constexpr RRLayout LY = rr_layout(nq, nv, nu, nbody, nM, ncon);
   static constexpr int o_qpos = LY.o_qpos, o_qvel = LY.o_qvel, o_act = LY.o_act, o_ctrl = LY.o_ctrl, o_xpos = LY.o_xpos, o_xquat = LY.o_xquat,
                        o_cinert = LY.o_cinert, o_cdof = LY.o_cdof, o_cvel = LY.o_cvel, o_qLD = LY.o_qLD, o_vec = LY.o_vec,
                        o_x = LY.o_x, o_arm = LY.o_arm, o_warm = LY.o_warm, o_qact = LY.o_qact, o_jlist = LY.o_jlist,
                        lds_floats = LY.lds_floats;
-  __host__ __device__ RRDimsRodent(const RRDims& d) : RRDims(d) {}
+  __host__ __device__ RRDimsFixed(const RRDims& d) : RRDims(d) {}
   static bool matches(const RRDims& d) {
     const RRDims& r = d;
     return r.nq == nq && r.nv == nv && r.nu == nu && r.nbody == nbody && r.njnt == njnt && r.nM == nM && r.ncon == ncon && r.dmax == dmax &&
@@ -113,6 +118,8 @@ struct RRDimsRodent : RRDims {
            r.o_warm == o_warm && r.o_qact == o_qact && r.o_jlist == o_jlist && r.lds_floats == lds_floats;
   }
 };
+typedef RRDimsFixed<66, 59, 1263> RRDimsRodent;       // rodent_optimized.xml (the benchmark model)
+typedef RRDimsFixed<67, 57, 1279> RRDimsRodentNew;    // rodent_new.xml (the env's default model [REF Rodent_Env_Brax.py:16]) == one replica of rodent_pair.xml
 
 // Table pointers carry the global address space in their type, so every table access is a global_load (never flat).
 typedef const int __attribute__((address_space(1)))* rr_gi;
@@ -379,12 +386,19 @@ __device__ __forceinline__ BodyC load_bodyc(const RRTables& T, int b, int nbody)
 #define RR_REP_KIN 0
 #endif
 typedef float rr_f2 __attribute__((ext_vector_type(2)));
-template <int NBS, int NVS, int NCS, class DT, bool NEWTON = false>
+// PAIR: the model is two identical trees that share no constraint (rodent_pair.xml: M block-diagonal, floor contacts only); the
+// workgroup is TWO wavefronts, wave r steps replica r on the tables of one replica in its own LDS region, and the only coupling is the
+// CG solver's scalars (cost, gradient norm, line-search sums, Polak-Ribiere beta): every such wave sum is followed by an exchange
+// through LDS (solver_sum_n), after which both waves hold the same totals and take the same branches.
+template <int NBS, int NVS, int NCS, class DT, bool NEWTON = false, bool PAIR = false>
 struct Wave {
   const DT& D;
   const RRTables& T;
   int lane;               // re-derived (opaquely) at the head of every substep: see RR_FRAME_LOCAL in the kernel
   float* const lds;
+  int rep = 0;            // PAIR: this wave's replica (wave-uniform)
+  int xpar = 0;           // PAIR: parity of the next exchange (two buffers: a wave may be one exchange ahead of its partner)
+  float* s_xc = nullptr;  // PAIR: exchange cells [2 parities][2 waves][8] behind the two replicas' regions
   // LDS regions.  Aliases (liveness): s_crb == s_cinert (accumulated in place once cinert has been
   // consumed / written out), s_cacc|s_cfrc and the sin/cos scratch live in the region that later holds qLD,
   // s_buf reuses xpos|xquat after the contact geometry has been taken.
@@ -431,7 +445,7 @@ struct Wave {
   }
 
   __device__ Wave(const DT& d, const RRTables& t, float* l)
-      : D(d), T(t), lane(threadIdx.x), lds(l) {
+      : D(d), T(t), lane(threadIdx.x & (RR_LANES - 1)), lds(l) {
     s_qpos = l + d.o_qpos; s_qvel = l + d.o_qvel; s_act = l + d.o_act; s_ctrl = l + d.o_ctrl;
     s_xpos = l + d.o_xpos; s_xquat = l + d.o_xquat; s_cinert = l + d.o_cinert; s_crb = s_cinert;
     s_cdof = l + d.o_cdof; s_cvel = l + d.o_cvel; s_qLD = l + d.o_qLD;
@@ -463,6 +477,29 @@ struct Wave {
   }
   // wave-uniform predicate -> scalar branch
   static __device__ __forceinline__ bool uni(bool p) { return __builtin_amdgcn_readfirstlane((int)p) != 0; }
+  // A sum the SOLVER branches on (cost, gradient norm, line-search sums, beta): the wave sum, and for PAIR instances the total of the two
+  // replicas' wave sums, formed as [wave 0] + [wave 1] by BOTH waves (identical bits, hence identical branches and matching barriers).
+  // One s_barrier per exchange: the cells alternate between two buffers, and a wave can reach exchange k + 2 (same buffer as k) only
+  // after its partner has passed the barrier of k + 1, i.e. has read the cells of k.
+  template <int K>
+  __device__ __forceinline__ void solver_sum_n(float* v) {
+    wave_sum_n<K>(v);
+    if (PAIR) {
+      static_assert(K <= 8, "exchange cells");
+      float* mine = s_xc + 16 * xpar + 8 * rep;
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) mine[k] = v[k];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const float* c = s_xc + 16 * xpar;
+#pragma unroll
+      for (int k = 0; k < K; ++k) v[k] = c[k] + c[8 + k];
+      xpar ^= 1;
+    }
+  }
+  __device__ __forceinline__ float solver_sum(float v) { float t[1] = {v}; solver_sum_n<1>(t); return t[0]; }
 
   // ---------------------------------------------------------------- A-1 kinematics (pointer doubling)
   // Every body first builds its LOCAL transform (parent frame -> body, all joints applied) in parallel; world
@@ -953,7 +990,7 @@ struct Wave {
       if (d < D.nv) s_qLD[2 * (opaque(dofc1[s]) & 0xFFFF) + 1] += D.dt * T.dof_f[16 * d + 1];
     }
     sync();
-    run_levels<true>(T.factor3, D.nfac);
+    run_levels<true>(PAIR ? T.factor3 + rep * D.fac_stride : T.factor3, D.nfac);
     sync();
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
@@ -980,7 +1017,7 @@ struct Wave {
   // of them per factorisation; with W they become two independent sparse products (ldl_solve).  Gauss-Jordan by depth
   // levels, shallow -> deep (k_linv): when the dofs k of a level are processed every descendant row i does
   // W_ia -= W_ik W_ka over the strict ancestors a of k; W_ik still holds L_ik (only deeper levels write it), row k is final.
-  __device__ __forceinline__ void invert() { run_levels<false>(T.linv, D.ninv); }
+  __device__ __forceinline__ void invert() { run_levels<false>(PAIR ? T.linv + rep * D.inv_stride : T.linv, D.ninv); }
 
   // x <- (L' D L)^-1 x = U D^-1 U' x  [MuJoCo mj_solveLD] with the explicit inverse factor U = I - W (see invert): no
   // dependent chain, no atomics.  U' b sums column j over its descendants i (a contiguous DFS range, entry (i, j) at
@@ -1421,7 +1458,7 @@ struct Wave {
       qfrc_con[s] = qcs;
       part[1] += (Ma[s] - qfrc_smooth[s]) * (qacc[s] - qacc_smooth[s]);
     }
-    wave_sum_n<2>(part);
+    solver_sum_n<2>(part);
     gauss = 0.5f * part[1];
     prev_cost = cost;
     cost = 0.5f * part[0] + gauss;
@@ -1584,7 +1621,7 @@ struct Wave {
           if (jr + alpha[i] * jv < 0) { q[NQ * i] += q1; q[NQ * i + 1] += q2; if (COST) q[NQ * i + 2] += q0; }
       }
     }
-    wave_sum_n<NQ * NP>(q);
+    solver_sum_n<NQ * NP>(q);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const float q1 = qg[1] + q[NQ * i], q2 = qg[2] + q[NQ * i + 1];
@@ -1648,8 +1685,8 @@ struct Wave {
         if (idx < R) { rjr[r] = s_cinert[idx]; rjv[r] = s_cvel[idx]; rD[r] = s_buf[idx]; }
       }
     }
-    wave_sum_n<4>(red);
-    const float smag = sqrtf(red[0]) * D.meaninertia * (float)(D.nv > 1 ? D.nv : 1);
+    solver_sum_n<4>(red);
+    const float smag = sqrtf(red[0]) * D.meaninertia * (float)D.nv_scale;
     const float gtol = D.tolerance * D.ls_tolerance * smag;
     const float qg[3] = {gauss, red[1] - red[2], 0.5f * red[3]};
     stamp<PROF>(17);
@@ -1703,7 +1740,7 @@ struct Wave {
   // [UP mjx solver.solve] primal CG with warm start; returns the iteration count
   template <bool PROF>
   __device__ __forceinline__ int solve() {
-    const float scale = 1.0f / (D.meaninertia * (float)(D.nv > 1 ? D.nv : 1));
+    const float scale = 1.0f / (D.meaninertia * (float)D.nv_scale);
     // warm start [UP mjx solver.solve]: cost at qacc_smooth, cost at qacc_warmstart, then the full context at the cheaper
     // of the two.  One copy of the evaluation code, driven by a wave-uniform phase counter.
     float cost_smooth = 0.0f;
@@ -1729,7 +1766,7 @@ struct Wave {
       float g2 = 0.0f;
 #pragma unroll
       for (int s = 0; s < NVS; ++s) g2 += grad[s] * grad[s];
-      const float gradient = sqrtf(wave_sum(g2)) * scale;
+      const float gradient = sqrtf(solver_sum(g2)) * scale;
       bool done = niter >= D.iterations;
       done |= improvement < D.tolerance;
       done |= gradient < D.tolerance;
@@ -1749,7 +1786,7 @@ struct Wave {
       float bt[2] = {0.0f, gg};
 #pragma unroll
       for (int s = 0; s < NVS; ++s) bt[0] += grad[s] * (Mgrad[s] - pm[s]);
-      wave_sum_n<2>(bt);
+      solver_sum_n<2>(bt);
       const float beta = NEWTON ? 0.0f : fmaxf(0.0f, bt[0] / fmaxf(RR_MINVAL, bt[1]));      // Newton: search = -Mgrad
 #pragma unroll
       for (int s = 0; s < NVS; ++s) { search[s] = -Mgrad[s] + beta * search[s]; mv[s] = -grad[s] + beta * mv[s]; }
@@ -1911,22 +1948,29 @@ __device__ __forceinline__ void rr_actor_step(const RRIO& io, const DT& D, int l
 // step lasts as long as its slowest environment; over ten unsynchronised steps the slowest SUM is 6.5 % below ten slowest steps,
 // tools/tail_probe.py), the state stays in LDS from step to step, and the Episode + AutoReset wrappers
 // (brax.envs.wrappers.training; rr_wrap_episode_autoreset is their one-launch form) are applied in place.
-template <int NBS, int NVS, int NCS, bool PROF, bool DBG, class DT, bool NEWTON = false, bool UNROLL = false, bool ACTOR = false>
-__global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(const RRDims Dk, const RRTables T, const RRIO io_kernarg, const int num_envs,
+// PAIR (see Wave): 128 threads = one wavefront per replica of a two-tree model; Dk / T describe ONE replica (nv_scale = the model's
+// dof count), the state arrays are the model's ([N][2 nq] ...: replica r of environment e is row 2 e + r of an [2 N][nq] array).
+// Physics only (pipeline_init / pipeline_step: no env epilogue, no optional outputs, no debug dump).
+template <int NBS, int NVS, int NCS, bool PROF, bool DBG, class DT, bool NEWTON = false, bool UNROLL = false, bool ACTOR = false, bool PAIR = false>
+__global__ __launch_bounds__((PAIR ? 2 : 1) * RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(const RRDims Dk, const RRTables T, const RRIO io_kernarg, const int num_envs,
                                                            const int n_frames) {
+  static_assert(!PAIR || (!PROF && !DBG && !NEWTON && !UNROLL && !ACTOR), "PAIR: production physics instance only");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int env = blockIdx.x;
   if (env >= num_envs) return;
   // the level schedules address LDS by absolute byte address: the dynamic segment must start at 0, i.e. the kernel has no static
   // LDS -- checked on the HOST for every instance a batch may launch (rr_batch_create: hipFuncGetAttributes().sharedSizeBytes == 0)
   const DT D(Dk);
-  Wave<NBS, NVS, NCS, DT, NEWTON> w(D, T, lds);
-  int lane = threadIdx.x;
+  const int wrep = PAIR ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+  Wave<NBS, NVS, NCS, DT, NEWTON, PAIR> w(D, T, PAIR ? lds + wrep * (D.lds_bytes_rep >> 2) : lds);
+  int lane = threadIdx.x & (RR_LANES - 1);
+  if (PAIR) { w.rep = wrep; w.s_xc = lds + 2 * (D.lds_bytes_rep >> 2); }
   RRIO io = load_io();
   if (io.env_map) {          // a permutation of 0 .. num_envs-1 (host-checked length); environments are independent, so the mapping
     env = __builtin_amdgcn_readfirstlane(io.env_map[env]);   // only decides which two of them share a SIMD
     if ((unsigned)env >= (unsigned)num_envs) return;
   }
+  const int senv = PAIR ? 2 * env + wrep : env;      // row of this wave's replica in the state arrays
   if (DBG) {   // the re-read block must be the real parameter, word for word; on a mismatch say so in the dump and touch nothing else
     const RRIO ref_io = io_kernarg;
     bool same = true;
@@ -1952,7 +1996,7 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
   float xq1[4] = {1, 0, 0, 0};   // xquat of body 1 at the last forward pass (obs: xmat[1])
  for (int ut = 0; ut < nsteps; ++ut) {
   if (UNROLL) { lane = opaque(lane); w.lane = lane; asm volatile("" : "+s"(env)); io = load_io(); }
-  const size_t ctrl_at = UNROLL ? ((size_t)ut * num_envs + env) * D.nu : (size_t)env * D.nu;
+  const size_t ctrl_at = UNROLL ? ((size_t)ut * num_envs + env) * D.nu : (size_t)senv * D.nu;
   if (ACTOR) {
     if (ut == 0) {       // the observation the rollout starts from is row 0 of the env's trajectory
       for (int i = lane; i < D.obs_dim; i += RR_LANES) io.t_obs[rr_traj_obs(io, num_envs, env, 0, 0) * D.obs_dim + i] = io.a_obs_in[(size_t)env * D.obs_dim + i];
@@ -1967,15 +2011,15 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
   }
   // ---- load state (a multi-step rollout keeps it in LDS after its first step)
   if (!UNROLL || ut == 0) {
-    for (int i = lane; i < D.nq; i += RR_LANES) w.s_qpos[i] = io.qpos_in[(size_t)env * D.nq + i];
-    for (int i = lane; i < D.nv; i += RR_LANES) w.s_qvel[i] = io.qvel_in[(size_t)env * D.nv + i];
-    for (int i = lane; i < D.nu; i += RR_LANES) w.s_act[i] = io.act_in[(size_t)env * D.nu + i];
+    for (int i = lane; i < D.nq; i += RR_LANES) w.s_qpos[i] = io.qpos_in[(size_t)senv * D.nq + i];
+    for (int i = lane; i < D.nv; i += RR_LANES) w.s_qvel[i] = io.qvel_in[(size_t)senv * D.nv + i];
+    for (int i = lane; i < D.nu; i += RR_LANES) w.s_act[i] = io.act_in[(size_t)senv * D.nu + i];
   }
   for (int i = lane; i < D.nu; i += RR_LANES) w.s_ctrl[i] = io.ctrl ? io.ctrl[ctrl_at + i] : 0.0f;
 #pragma unroll
   for (int s = 0; s < NVS; ++s) {
     const int d = lane + RR_LANES * s;
-    if ((!UNROLL || ut == 0) && d < D.nv) w.s_warm[d] = io.warm_in[(size_t)env * D.nv + d];
+    if ((!UNROLL || ut == 0) && d < D.nv) w.s_warm[d] = io.warm_in[(size_t)senv * D.nv + d];
     if (d < D.nv) {
       auto di = T.dof_i + RR_DOFI * d;
       w.dofc0[s] = (di[3] & 255) | ((di[2] & 15) << 8) | ((di[9] & 15) << 12) | ((di[0] & 255) << 16) | ((T.body_i[RR_BODYI * di[0]] & 255) << 24);
@@ -2159,18 +2203,18 @@ __global__ __launch_bounds__(RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(c
   io = load_io();
   if (PROF && io.prof && lane == 0) for (int i = 0; i < RR_NPH; ++i) io.prof[(size_t)env * RR_NPH + i] = w.pt[i];
   if (UNROLL) u_work += (unsigned)w.work;        // a multi-step launch reports the work of all its steps
-  if (io.cost && lane == 0) io.cost[env] = UNROLL ? u_work : (unsigned)w.work;
+  if (io.cost && lane == 0 && wrep == 0) io.cost[env] = UNROLL ? u_work : (unsigned)w.work;
   // ---- write back state (a multi-step rollout writes it once, after the wrappers of its last step: see below)
   if (!UNROLL) {
-    for (int i = lane; i < D.nq; i += RR_LANES) io.qpos[(size_t)env * D.nq + i] = w.s_qpos[i];
-    for (int i = lane; i < D.nv; i += RR_LANES) io.qvel[(size_t)env * D.nv + i] = w.s_qvel[i];
-    for (int i = lane; i < D.nu; i += RR_LANES) io.act[(size_t)env * D.nu + i] = w.s_act[i];
+    for (int i = lane; i < D.nq; i += RR_LANES) io.qpos[(size_t)senv * D.nq + i] = w.s_qpos[i];
+    for (int i = lane; i < D.nv; i += RR_LANES) io.qvel[(size_t)senv * D.nv + i] = w.s_qvel[i];
+    for (int i = lane; i < D.nu; i += RR_LANES) io.act[(size_t)senv * D.nu + i] = w.s_act[i];
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
       const int d = lane + RR_LANES * s;
       if (d < D.nv) {
-        io.warm[(size_t)env * D.nv + d] = w.s_warm[d];
-        if (io.o_qfrc_actuator) io.o_qfrc_actuator[(size_t)env * D.nv + d] = w.s_qact[d];
+        io.warm[(size_t)senv * D.nv + d] = w.s_warm[d];
+        if (io.o_qfrc_actuator) io.o_qfrc_actuator[(size_t)senv * D.nv + d] = w.s_qact[d];
       }
     }
   }

@@ -21,6 +21,110 @@ def _slots(n):
     return max(1, (int(n) + LANES - 1) // LANES)
 
 
+def replica_model(m):
+    """A model of two identical kinematic trees (`<replicate count="2">`, rodent_pair.xml [REF models/rodent_pair.xml:163-500]) seen as
+    ONE tree: the MuJoCo-named tables of replica 0 with ids re-based (world body 0 kept), or None when the model is not of that
+    shape.  The two trees share no constraint (M block-diagonal, floor contacts only), so the step kernel can give each replica its own
+    wavefront running on these tables and couple the two only through the solver's scalar sums (csrc/rr_kernel.h, PAIR instances).
+    Every table that enters the dynamics must be identical for the two replicas (checked); what differs -- the root's qpos0 -- does
+    not enter them (a free joint takes its pose from qpos)."""
+    nb, nv, njnt, nq, nu, ncon = (int(m[k]) for k in ("nbody", "nv", "njnt", "nq", "nu", "ncon"))
+    roots = sorted(set(int(r) for r in m["body_rootid"][1:]))
+    if len(roots) != 2 or (nb - 1) % 2 or nv % 2 or njnt % 2 or nq % 2 or nu % 2 or ncon % 2 or int(m["na"]) != nu:
+        return None
+    hb, hv, hj, hq, hu = (nb - 1) // 2, nv // 2, njnt // 2, nq // 2, nu // 2
+    if roots != [1, 1 + hb]:
+        return None
+    FREE = 0
+    if m["jnt_type"][0] != FREE or m["jnt_type"][hj] != FREE or m["body_parentid"][1] != 0 or m["body_parentid"][1 + hb] != 0:
+        return None
+    h = {}
+
+    def same(a, b, what):
+        a, b = np.asarray(a), np.asarray(b)
+        ok = a.shape == b.shape and (np.allclose(a, b, rtol=1e-7, atol=1e-12) if a.dtype.kind == "f" else np.array_equal(a, b))     # float32 on disk
+        if not ok:
+            raise ValueError(f"replicas differ in {what}: the two-wave instance needs identical trees")
+
+    def body(name, rebase=None, root_free=False):
+        a = np.asarray(m[name])
+        r0, r1 = a[1:1 + hb].copy(), a[1 + hb:1 + 2 * hb].copy()
+        if rebase is not None:
+            r0, r1 = rebase(r0, 0), rebase(r1, 1)
+        if root_free:             # the pose of a free-joint body comes from qpos
+            r1[0] = r0[0]
+        same(r0, r1, name)
+        h[name] = np.concatenate([a[:1], r0])
+
+    def rows(name, n, rebase=None):
+        a = np.asarray(m[name])
+        r0, r1 = a[:n].copy(), a[n:2 * n].copy()
+        if rebase is not None:
+            r0, r1 = rebase(r0, 0), rebase(r1, 1)
+        same(r0, r1, name)
+        h[name] = r0
+
+    reb = lambda step, keep=None: (lambda x, r: np.where(x == keep, x, x - r * step) if keep is not None else x - r * step)
+    body("body_parentid", lambda x, r: np.where(x > 0, x - r * hb, 0))
+    body("body_rootid", reb(hb))
+    body("body_depth"); body("body_subtreemass"); body("body_jntnum"); body("body_dofnum"); body("body_mass"); body("body_inertia")
+    body("body_jntadr", reb(hj, -1)); body("body_dofadr", reb(hv, -1)); body("body_lastdof", reb(hv, -1))
+    body("body_pos", root_free=True); body("body_quat", root_free=True); body("body_ipos"); body("body_iquat"); body("body_invweight0")
+    rows("jnt_type", hj); rows("jnt_pos", hj); rows("jnt_axis", hj); rows("jnt_limited", hj); rows("jnt_stiffness", hj)
+    rows("jnt_range", hj); rows("jnt_solref", hj); rows("jnt_solimp", hj)
+    rows("jnt_qposadr", hj, reb(hq)); rows("jnt_dofadr", hj, reb(hv)); rows("jnt_bodyid", hj, reb(hb))
+    rows("dof_parentid", hv, reb(hv, -1)); rows("dof_depth", hv); rows("dof_jntid", hv, reb(hj)); rows("dof_bodyid", hv, reb(hb))
+    rows("dof_armature", hv); rows("dof_damping", hv); rows("dof_invweight0", hv)
+    hM = int(m["nM"]) // 2
+    rows("dof_Madr", hv, reb(hM))
+    rows("actuator_dofadr", hu, reb(hv)); rows("actuator_gainprm0", hu); rows("actuator_biasprm", hu); rows("actuator_dynprm0", hu)
+    rows("actuator_ctrlrange", hu)
+    # qpos0 / qpos_spring: hinge entries identical, the free joint's 7 are not used by the dynamics
+    q0, q1 = np.asarray(m["qpos0"])[:hq].copy(), np.asarray(m["qpos0"])[hq:].copy()
+    q1[:7] = q0[:7]
+    same(q0, q1, "qpos0 (hinges)")
+    h["qpos0"] = q0
+    s0, s1 = np.asarray(m["qpos_spring"])[:hq].copy(), np.asarray(m["qpos_spring"])[hq:].copy()
+    s1[:7] = s0[:7]
+    same(s0, s1, "qpos_spring (hinges)")
+    h["qpos_spring"] = s0
+    adr = np.asarray(m["dof_ancadr"])
+    a0 = np.asarray(m["dof_anc"])[adr[0]:adr[hv]]
+    a1 = np.asarray(m["dof_anc"])[adr[hv]:adr[2 * hv]] - hv
+    same(a0, a1, "dof_anc")
+    same(adr[:hv + 1], adr[hv:] - adr[hv], "dof_ancadr")
+    h["dof_anc"], h["dof_ancadr"] = a0.copy(), adr[:hv + 1].copy()
+    # contacts of each replica (the pair's list is grouped by geom type first, so a replica's contacts are not contiguous)
+    cb = np.asarray(m["con_body2"])
+    if np.any(np.asarray(m["con_body1"]) != 0):
+        return None
+    sel = [np.nonzero((cb >= 1 + r * hb) & (cb < 1 + (r + 1) * hb))[0] for r in (0, 1)]
+    if len(sel[0]) != ncon // 2 or len(sel[1]) != ncon // 2:
+        return None
+    for name in ("con_kind", "con_friction", "con_invweight", "con_solref", "con_solimp"):
+        same(np.asarray(m[name])[sel[0]], np.asarray(m[name])[sel[1]], name)
+        h[name] = np.asarray(m[name])[sel[0]].copy()
+    same(cb[sel[0]], cb[sel[1]] - hb, "con_body2")
+    same(np.asarray(m["con_lastdof"])[sel[0]], np.asarray(m["con_lastdof"])[sel[1]] - hv, "con_lastdof")
+    g2 = np.asarray(m["con_geom2"])
+    for name in ("geom_pos", "geom_quat", "geom_size"):
+        same(np.asarray(m[name])[g2[sel[0]]], np.asarray(m[name])[g2[sel[1]]], name + " of the colliding geoms")
+    same(np.asarray(m["con_geom1"])[sel[0]], np.asarray(m["con_geom1"])[sel[1]], "con_geom1")
+    h["con_body1"] = np.zeros(ncon // 2, np.int32)
+    h["con_body2"], h["con_lastdof"] = cb[sel[0]].copy(), np.asarray(m["con_lastdof"])[sel[0]].copy()
+    h["con_geom1"], h["con_geom2"] = np.asarray(m["con_geom1"])[sel[0]].copy(), g2[sel[0]].copy()
+    jadr = np.zeros(ncon // 2 + 1, np.int32)
+    for c, d in enumerate(h["con_lastdof"]):
+        jadr[c + 1] = jadr[c] + 3 * (h["dof_depth"][d] + 1 if d >= 0 else 0)
+    h["con_jadr"] = jadr
+    for name in ("geom_pos", "geom_quat", "geom_size", "opt_impratio"):      # indexed by the (unchanged) geom ids
+        h[name] = m[name]
+    h.update(nbody=np.int32(1 + hb), nv=np.int32(hv), njnt=np.int32(hj), nq=np.int32(hq), nu=np.int32(hu), na=np.int32(hu),
+             nM=np.int32(hM), ncon=np.int32(ncon // 2))
+    h["_contacts_of_replica"] = np.stack(sel).astype(np.int32)
+    return h
+
+
 def build_kernel_tables(m):
     nb, nv, njnt, nM = int(m["nbody"]), int(m["nv"]), int(m["njnt"]), int(m["nM"])
     ncon = int(m["ncon"])

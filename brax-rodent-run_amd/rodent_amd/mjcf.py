@@ -580,8 +580,16 @@ def compile_mjcf(xml_path: str, *, iterations: int = 6, ls_iterations: int = 6,
     hip_ok = (not any(trn_type)) and int(m["ncon"]) > 0 and any(t == FREE for t in jnt_type)
     m["hip_supported"] = np.int32(hip_ok)
     if hip_ok:
-        from .ktables import build_kernel_tables
+        from .ktables import build_kernel_tables, replica_model
         m.update(build_kernel_tables(m))
+        # two identical trees (rodent_pair.xml): the kernel tables of ONE replica as `h_*` (h_k_dof_i, ...) + its dims `h_dims`; the
+        # library then steps such a model with one wavefront per replica (csrc/rr_kernel.h, PAIR instances)
+        half = replica_model(m)
+        if half is not None:
+            hk = build_kernel_tables(half)
+            m.update({"h_" + k: v for k, v in hk.items()})
+            m["h_dims"] = np.asarray([half[k] for k in ("nq", "nv", "nu", "nbody", "njnt", "nM", "ncon")] + [int(half["dof_depth"].max())], np.int32)
+            m["h_con_of_replica"] = half["_contacts_of_replica"]
     return m
 
 

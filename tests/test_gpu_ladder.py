@@ -61,6 +61,42 @@ def test_teacher_forced_substeps_rodent_pair(oracle_built):
     parity.assert_substep_criteria(out)
 
 
+def test_rodent_pair_two_wave_instance(oracle_built):
+    """The production path of a two-tree model: one wavefront per replica, coupled only through the solver's scalar sums
+    (rr_kernel.h PAIR; SURVEY.md config 5 [REF models/rodent_pair.xml:163-500]).  (1) teacher-forced substeps against the float64 oracle by
+    the state criteria; (2) against the generic one-wave instance (RR_PAIR_WAVES=0) on the same inputs: two float32 evaluations of one
+    map, equal to float32 round-off amplified by the solver -- the same bound class as (1); (3) pipeline_init and a 10-substep launch."""
+    from rodent_amd import assets, hip
+    N = 8
+    seq, A, tab = parity.rollout_inputs("rodent_pair", N, 200, (8, 8), seed=33, z_range=(-1.0, 1.0))
+    impl = HipImpl("rodent_pair", N, (8, 8), False)
+    out = parity.substep_ladder(NoDiscrete(impl, A), seq, A, parity.OracleImpl("rodent_pair", N, "f32", (8, 8)))
+    _report("substeps_cg8_pair_two_wave", out)
+    parity.check_quantiles(out["quantiles"], parity.SUBSTEP_FLOORS)
+    os.environ["RR_PAIR_WAVES"] = "0"
+    try:
+        generic = HipImpl("rodent_pair", N, (8, 8), False)
+    finally:
+        del os.environ["RR_PAIR_WAVES"]
+    err = {k: [] for k in ("qpos", "qvel")}
+    gap = {k: [] for k in ("qpos", "qvel")}
+    for st, ctrl in seq[:60]:
+        a, b, w = impl.substep(st, ctrl), generic.substep(st, ctrl), A.substep(st, ctrl)
+        for k in err:
+            err[k].append(np.abs(a[k] - b[k]).max(1)); gap[k].append(np.abs(b[k] - w[k]).max(1))
+    rows = []
+    for k in err:
+        rows += parity.quantile_rows(k, np.concatenate(err[k]), np.concatenate(gap[k]))
+    _report("pair_two_wave_vs_generic", rows)
+    parity.check_quantiles(rows, parity.SUBSTEP_FLOORS)
+    # n_frames = 10 and the forward-only launch go through the same instance
+    ds = impl._dev(seq[0][0])
+    impl.batch.pipeline_init(ds)
+    impl.batch.pipeline_step(ds, torch.tensor(seq[0][1], dtype=torch.float32, device=DEV), 10)
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(v).all() for v in ds.values())
+
+
 def test_teacher_forced_substeps_newton(oracle_built):
     """solver = Newton (the Hessian M + J'DJ factored per iteration through the level schedules of M)."""
     N, it = 16, (4, 8)
