@@ -53,30 +53,45 @@ def host_cores():
     return min(n, int(os.environ.get("RR_CPU_THREADS", "16")))
 
 
-def pmc_traffic():
-    """HBM-side bytes per launch of the step kernel from the latest committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE are collected in their own runs, tools/pmc_traffic.py); None when no summary is present."""
+def pmc_traffic(env_steps_per_launch):
+    """HBM-side bytes per LAUNCH of the step kernel: NOT measured by this run (rocprofv3 PMC passes cannot run inside it) but read
+    from the latest committed summary (FETCH_SIZE and WRITE_SIZE collected in their own runs of the bench command, tools/
+    profile_round3.sh -> tools/pmc_traffic.py).  Returned only when that summary was taken in the SAME launch mode (env steps per
+    launch, hence the same kernel instance) as this run; the source file and its mode always go into the line (`traffic_source`)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
-        return None
+        return None, None
     try:
-        return float(json.load(open(files[-1]))["traffic_bytes_per_launch"])
+        d = json.load(open(files[-1]))
+        mode = int(d.get("env_steps_per_launch", 1))
+        src = f"profiles/{os.path.basename(files[-1])} (rocprofv3 --pmc passes of `{d.get('command', 'bench.py --unroll 1 --no-graph')}`: {mode} env step(s) per launch)"
+        if mode != env_steps_per_launch:
+            return None, src + f"; this run launches {env_steps_per_launch} env steps at a time: not comparable, traffic omitted"
+        return float(d["traffic_bytes_per_launch"]), src
     except Exception:
-        return None
+        return None, None
 
 
-def sq_counters():
-    """VALU-busy share and instructions per env-step of the step kernel from the latest committed SQ counter pass
-    (tools/pmc_sq.sh -> profiles/r*_sq.json); the kernel is issue / latency bound, so these -- not the HBM fraction the
-    north star asks for -- are the numbers that track kernel quality."""
+def sq_counters(env_steps_per_launch, envs):
+    """VALU-busy share and instructions per env-step of the step kernel from the latest committed SQ counter pass (profiles/r*_sq.json;
+    NOT measured by this run -- `counters_source` names the file and the launch mode it was taken in); the kernel is issue / latency
+    bound, so these -- not the HBM fraction the north star asks for -- are the numbers that track kernel quality.  valu_issue_floor_ms:
+    the time one bench step would take if the SIMDs' vector ALUs never idled = VALU instructions per env-step x envs per SIMD x 4 cycles
+    (wave64 on a 16-lane-per-cycle... SIMD: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU measures 4.1) / 2.4 GHz."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq.json")))
     if not files:
         return {}
     try:
         d = json.load(open(files[-1]))
-        return {k: d[k] for k in ("valu_busy_frac", "instructions_per_env_step", "valu_instructions_per_env_step", "lds_bank_conflict_frac") if k in d}
+        out = {k: d[k] for k in ("valu_busy_frac", "instructions_per_env_step", "valu_instructions_per_env_step", "lds_bank_conflict_frac") if k in d}
+        mode = int(d.get("env_steps_per_launch", 1))
+        out["counters_source"] = (f"profiles/{os.path.basename(files[-1])} ({mode} env step(s) per launch"
+                                  + ("" if mode == env_steps_per_launch else f"; this run: {env_steps_per_launch}") + ")")
+        if "valu_instructions_per_env_step" in d:
+            out["valu_issue_floor_ms"] = d["valu_instructions_per_env_step"] * (envs / 1024.0) * 4.0 / 2.4e9 * 1e3     # 256 CUs x 4 SIMDs
+        return out
     except Exception:
         return {}
 
@@ -459,8 +474,13 @@ def main():
         if args.config == 3 and launches and extra.get("step_kernel_time_source", "").startswith("hip events"):
             per_launch = max(1.0, extra["rollout_steps_per_env"] / launches)
         achieved = bytes_per_env_step * (N // concurrent) * per_launch * concurrent / avg_kernel_s / 1e9
+        traffic, traffic_src = pmc_traffic(int(per_launch)) if args.config == 2 else (None, None)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic() if args.config == 2 else None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                # `achieved` prices every env step at SURVEY.md 8(d)'s algorithmic 7180 B (state in + out, action, observation); a multi-step
+                # launch keeps the state on chip, so the bytes it must move per env step are the action and the observation only
+                "achieved_basis": "SURVEY.md 8(d) algorithmic bytes x env steps of the launch / launch duration (HIP events, live)",
+                "bytes_moved_per_env_step_multi_step_launch": 4 * (d.nu + (d.obs_dim + 2 if args.config != 5 else 0)),
                 # avg_kernel_ms: kernel time of ONE bench step (all envs advance one step) = launch duration / env steps per launch
                 # (sub-batch launches run side by side); avg_launch_ms: the duration of a launch itself, as rocprofv3 lists it
                 "kernel": "rr_step_kernel", "avg_kernel_ms": avg_kernel_s * 1e3 / per_launch, "avg_launch_ms": avg_kernel_s * 1e3, "launches": launches,
@@ -468,7 +488,7 @@ def main():
                 "algorithmic_bytes_per_env_step": bytes_per_env_step,
                 "limiter": "VALU issue + dependent LDS/L2 latency, not HBM (SURVEY.md 8(d)); see valu_busy_frac"}
         if args.config == 2:
-            roof.update(sq_counters())
+            roof.update(sq_counters(int(per_launch), N))
         out = {
             "metric": "env-steps/sec (whole node), rodent 2048 envs/GPU", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,

@@ -15,10 +15,10 @@ from . import jax_random
 
 
 @torch.no_grad()
-def eval_rollout(env, make_policy, params, steps: int = 500, seed: int = 0) -> np.ndarray:
+def eval_rollout(env, make_policy, params, steps: int = 500, seed: int = 0, record: Optional[list] = None) -> np.ndarray:
     """`env`: a `Rodent` with num_envs = 1 (the reference's jit_reset / jit_step pair).  Key handling as the launcher:
     `key = PRNGKey(seed); _, key = split(key); reset_rng, act_rng = split(key)`; the policy is deterministic.
-    Returns the rollout's qpos [steps + 1, nq] (float32)."""
+    Returns the rollout's qpos [steps + 1, nq] (float32).  `record` (tests): a list that receives (state, action, next_state) per step."""
     if env.num_envs != 1:
         raise ValueError("the evaluation rollout steps a single env (use env.with_num_envs(1))")
     key = jax_random.PRNGKey(seed)
@@ -30,7 +30,9 @@ def eval_rollout(env, make_policy, params, steps: int = 500, seed: int = 0) -> n
     for _ in range(steps):
         _, act_rng = jax_random.split(act_rng)
         ctrl, _ = policy(state.obs, None)
-        state = env.step(state, ctrl)
+        prev, state = state, env.step(state, ctrl)
+        if record is not None:
+            record.append((prev, ctrl, state))
         qposes.append(state.pipeline_state.qpos[0].clone())
     return torch.stack(qposes).cpu().numpy()
 

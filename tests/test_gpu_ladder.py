@@ -239,10 +239,13 @@ def test_np_ref_fixtures(model_name, oracle_built):
     np.testing.assert_array_equal(f("con_dist") < 0, g["fwd_con_dist"] < 0)
     np.testing.assert_array_equal(f("niter_cost")[:, 0].astype(int), g["fwd_cg8_niter"][:, 0].astype(int))
     worst["qacc"] = (rel(f("qacc"), g["fwd_cg8_qacc"]), 2e-4)
-    # one substep: the bound is 3x what the scalar float32 oracle loses on these very states (heavy-tailed: tests/parity.py)
-    B = parity.OracleImpl(model_name, n, "f32", (8, 8)).substep(st, g["in_ctrl"])
-    worst["qpos_substep"] = (float(np.abs(ds["qpos"].cpu().numpy() - g["sub_cg8_qpos"]).max()), 3 * float(np.abs(B["qpos"] - g["sub_cg8_qpos"]).max()) + 2e-7)
-    worst["qvel_substep"] = (float(np.abs(ds["qvel"].cpu().numpy() - g["sub_cg8_qvel"]).max()), 3 * float(np.abs(B["qvel"] - g["sub_cg8_qvel"]).max()) + 2e-5)
+    # one substep.  FIXED bounds, nothing of oracle/rodent_ref.c evaluated here (round 2 took 3x that oracle's float32 loss on these
+    # states, which tied the "never passed through rodent_ref.c" fixture to it again): the worst of the n <= 8 fixture states must stay
+    # within 3x the 99th percentile of the one-substep error over the 16 000 samples of the teacher-forced ladder
+    # (profiles/r02_parity_ladder.json substeps_cg8_*: qpos q99 1.7e-5 / 1.8e-5, qvel q99 8.6e-3 / 8.9e-3; the error is heavy-tailed --
+    # a contact switching inside the substep -- so the median, 1e-7 / 4e-5, is no bound for a maximum)
+    worst["qpos_substep"] = (float(np.abs(ds["qpos"].cpu().numpy() - g["sub_cg8_qpos"]).max()), 5e-5)
+    worst["qvel_substep"] = (float(np.abs(ds["qvel"].cpu().numpy() - g["sub_cg8_qvel"]).max()), 2.5e-2)
     print(model_name, {k: f"{v[0]:.2e}" for k, v in worst.items()})
     bad = {k: v for k, v in worst.items() if not v[0] <= v[1]}
     assert not bad, bad
@@ -276,3 +279,60 @@ def test_reset_matches_oracle_init(oracle_built):
     _report("reset", dict(rows=rows))
     floors = dict(obs_qpos=0.0, obs_qvel=0.0, obs_cinert=2e-7, obs_cvel=2e-6, obs_qfrc_actuator=2e-7, obs_track_local=2e-7, qacc_warmstart=2e-6)
     parity.check_quantiles(rows, floors)
+
+
+def test_timed_instance_at_timed_size_against_the_oracle(oracle_built):
+    """The kernel instance and batch size bench.py times -- `rr_env_unroll` (multi-step instance) on 2048 envs -- held to the float64
+    oracle DIRECTLY (round 2 tied it to the oracle only transitively: UNROLL == per-step calls bitwise at N = 96, per-step vs oracle at
+    N = 16): from a rollout state 12 steps in (contacts made), ONE T = 1 launch of all 2048 envs; 32 sampled envs are re-stepped by the
+    oracle from the same state and action.  C1: cur_frame exact, done exact away from the height thresholds, wrapper steps exact;
+    C3: every observation segment, qpos, qvel, reward within 3x the scalar float32 oracle's own distance (tests/parity.py)."""
+    from rodent_amd import envs, jax_random
+    from rodent_amd.envs import wrappers
+    N, EP = 2048, 150
+    track = util.synthetic_track()
+    env = envs.get_environment("rodent", track_pos=track, num_envs=N, xml_path="rodent_optimized.xml", iterations=8, ls_iterations=8, device=DEV)
+    wenv = wrappers.wrap(env, episode_length=EP, action_repeat=1)
+    g = torch.Generator(device=DEV).manual_seed(77)
+    st = wenv.reset(jax_random.split(jax_random.PRNGKey(21), N))
+    st = wenv.unroll(st, torch.rand(12, N, 30, device=DEV, generator=g) * 2 - 1)
+    a = torch.rand(1, N, 30, device=DEV, generator=g) * 2 - 1
+    before = {k: getattr(st.pipeline_state, k).cpu().numpy().astype(np.float64) for k in parity.STATE}
+    cf0 = st.info["cur_frame"].cpu().numpy().copy()
+    steps0, done0 = st.info["steps"].cpu().numpy().copy(), st.done.cpu().numpy().copy()
+    ns = wenv.unroll(st, a)
+    torch.cuda.synchronize()
+    pick = np.random.default_rng(5).choice(N, 32, replace=False)
+    sub = {k: v[pick] for k, v in before.items()}
+    act = a[0].cpu().numpy().astype(np.float64)[pick]
+    A = parity.OracleEnvImpl("rodent_optimized", 32, "f64", (8, 8), track)
+    B = parity.OracleEnvImpl("rodent_optimized", 32, "f32", (8, 8), track)
+    want, gap = A.env_step(sub, act, cf0[pick]), B.env_step(sub, act, cf0[pick])
+    np.testing.assert_array_equal(ns.info["cur_frame"].cpu().numpy()[pick], want["cur_frame"])
+    np.testing.assert_array_equal(ns.info["steps"].cpu().numpy()[pick], np.where(done0[pick] != 0, 0.0, steps0[pick]) + 1)
+    z = want["qpos"][:, 2]
+    near = (np.abs(z - 0.03) < 1e-3) | (np.abs(z - 0.5) < 1e-3)
+    over = ns.info["steps"].cpu().numpy()[pick] >= EP
+    hd = ns.done.cpu().numpy()[pick]
+    assert not ((hd != np.where(over, 1.0, want["done"])) & ~near).any()
+    keep = hd == 0                                            # envs that were auto-reset carry their first state, not the stepped one
+    assert keep.sum() >= 24
+    got_obs = ns.obs.cpu().numpy().astype(np.float64)[pick][keep]
+    seg = parity.obs_segments(mjcf_tables("rodent_optimized"))
+    rows = []
+    for k, s in seg.items():
+        sc = np.maximum(np.abs(want["obs"][keep][:, s]).max(1), 1e-3) if k == "cinert" else 1.0
+        rows += parity.quantile_rows("obs_" + k, np.abs(got_obs[:, s] - want["obs"][keep][:, s]).max(1) / sc,
+                                     np.abs(gap["obs"][keep][:, s] - want["obs"][keep][:, s]).max(1) / sc, qs=(0.5, 0.9))
+    for k in ("qpos", "qvel"):
+        gv = getattr(ns.pipeline_state, k).cpu().numpy().astype(np.float64)[pick][keep]
+        rows += parity.quantile_rows(k, np.abs(gv - want[k][keep]).max(1), np.abs(gap[k][keep] - want[k][keep]).max(1), qs=(0.5, 0.9))
+    rows += parity.quantile_rows("reward", np.abs(ns.reward.cpu().numpy()[pick][keep] - want["reward"][keep]), np.abs(gap["reward"][keep] - want["reward"][keep]), qs=(0.5, 0.9))
+    _report("timed_instance_2048", rows)
+    floors = dict(parity.ENV_FLOORS, obs_qpos=parity.ENV_FLOORS["qpos"], obs_qvel=parity.ENV_FLOORS["qvel"])
+    parity.check_quantiles(rows, floors)
+
+
+def mjcf_tables(name):
+    from rodent_amd import assets, mjcf
+    return mjcf.load_blob(assets.asset_path(name))
