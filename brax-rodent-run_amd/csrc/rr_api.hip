@@ -254,6 +254,7 @@ struct rr_batch {
   const int32_t* env_map = nullptr;     // rr_batch_set_schedule
   uint32_t* cost = nullptr;
   bool counted = false;                 // this batch is in m->live_batches
+  unsigned* progress = nullptr;         // pacing counter of multi-step launches (RRIO::progress); RR_PACE=0 turns pacing off
 };
 
 template <typename Ptr>
@@ -384,6 +385,15 @@ extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t devi
     if (e != hipSuccess) { rr_batch_destroy(b); return fail(RR_EHIP, std::string("hipFuncGetAttributes: ") + hipGetErrorString(e)); }
     if (fa.sharedSizeBytes != 0) { rr_batch_destroy(b); return fail(RR_EUNSUPPORTED, "rr_batch_create: a step-kernel instance has static LDS (the level schedules need the dynamic segment at address 0)"); }
   }
+  {
+    const char* pace = getenv("RR_PACE");
+    if (!(pace && pace[0] == '0')) {
+      void* p = nullptr;
+      HIPCHK(hipMalloc(&p, 64));
+      b->dev_allocs.push_back(p);
+      b->progress = (unsigned*)p;
+    }
+  }
   m->live_batches.fetch_add(1);
   b->counted = true;
   *out = b;
@@ -469,6 +479,10 @@ static int launch(rr_batch* b, const rr_state* st, const float* ctrl, int n_fram
     io.first_qpos = un->first.qpos; io.first_qvel = un->first.qvel; io.first_act = un->first.act; io.first_warm = un->first.qacc_warmstart;
     io.first_obs = un->first_obs; io.prev_done = un->prev_done; io.steps_in = un->steps_in; io.steps_out = un->steps_out;
     io.trunc_out = un->truncation_out; io.episode_length = un->episode_length; io.unroll_T = unroll_T;
+    if (b->progress && unroll_T > 1) {
+      HIPCHK(hipMemsetAsync(b->progress, 0, 4, b->stream));
+      io.progress = b->progress;
+    }
   }
   if (!kern) return fail(RR_EUNSUPPORTED, "launch: no diagnostic kernel instance for this model");
   io.prof = b->prof;

@@ -166,6 +166,11 @@ struct RRIO {
   float a_min_std;
   int a_nh;
   int a_seg, a_pad;                               // trajectory segment length L (unroll_T = U * L): the buffers are [U][N][L(+1)][...]
+  // PACING of a multi-step launch (nullable): one counter per launch, zeroed by the host; every environment adds 1 per finished env
+  // step, so counter / num_envs is the launch's average progress.  An environment behind it by more than a fraction of a step raises
+  // its wave priority (Wave::env_prio): the launch ends when its SLOWEST environment does, and a wave that outranks its SIMD partner
+  // runs at close to single-wave speed while the partner, which is ahead, has slack.  Timing only -- results are unaffected.
+  unsigned* progress;
   int mode;  // 0 = forward only (pipeline_init), 1 = step; bit 1 (2) = env epilogue as reset (obs only)
   int pad_;
 };
@@ -397,6 +402,7 @@ struct Wave {
   int lane;               // re-derived (opaquely) at the head of every substep: see RR_FRAME_LOCAL in the kernel
   float* const lds;
   int rep = 0;            // PAIR: this wave's replica (wave-uniform)
+  int lag_prio = 0;       // multi-step launches: priority level of an environment that is behind the launch's average progress (wave-uniform)
   int xpar = 0;           // PAIR: parity of the next exchange (two buffers: a wave may be one exchange ahead of its partner)
   float* s_xc = nullptr;  // PAIR: exchange cells [2 parities][2 waves][8] behind the two replicas' regions
   // LDS regions.  Aliases (liveness): s_crb == s_cinert (accumulated in place once cinert has been
@@ -470,9 +476,12 @@ struct Wave {
     __builtin_amdgcn_s_setprio(0);
     return;
 #endif
-    if (jnact >= 12) __builtin_amdgcn_s_setprio(3);          // (s_setprio takes an immediate)
-    else if (jnact >= 6) __builtin_amdgcn_s_setprio(2);
-    else if (jnact >= 2) __builtin_amdgcn_s_setprio(1);
+    // ... raised for an environment that has fallen behind the others of a multi-step launch (lag_prio, set by the kernel per env step)
+    const int by_weight = jnact >= 12 ? 3 : (jnact >= 6 ? 2 : (jnact >= 2 ? 1 : 0));
+    const int p = by_weight > lag_prio ? by_weight : lag_prio;
+    if (p >= 3) __builtin_amdgcn_s_setprio(3);          // (s_setprio takes an immediate)
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
     else __builtin_amdgcn_s_setprio(0);
   }
   // wave-uniform predicate -> scalar branch
@@ -2298,6 +2307,13 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * RR_LANES, (NVS >= 3 ? 1 : 2)) void
           float* nx = io.t_obs + rr_traj_obs(io, num_envs, env, tr.u + 1, 0) * D.obs_dim;
           for (int i = lane; i < D.obs_dim; i += RR_LANES) nx[i] = ob[i];
         }
+      }
+      if (io.progress && ut + 1 < nsteps) {
+        unsigned seen = 0;
+        if (lane == 0) seen = __hip_atomic_fetch_add(io.progress, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        seen = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);
+        const float behind = (float)seen / (float)num_envs - (float)(ut + 1);      // env steps behind the average environment
+        w.lag_prio = behind > 1.0f ? 3 : (behind > 0.6f ? 2 : (behind > 0.3f ? 1 : 0));
       }
       if (ut == nsteps - 1) {
         if (lane == 0) { io.done[env] = done2; io.steps_out[env] = u_steps; io.trunc_out[env] = trunc; }

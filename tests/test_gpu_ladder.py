@@ -284,8 +284,9 @@ def test_reset_matches_oracle_init(oracle_built):
 def test_timed_instance_at_timed_size_against_the_oracle(oracle_built):
     """The kernel instance and batch size bench.py times -- `rr_env_unroll` (multi-step instance) on 2048 envs -- held to the float64
     oracle DIRECTLY (round 2 tied it to the oracle only transitively: UNROLL == per-step calls bitwise at N = 96, per-step vs oracle at
-    N = 16): from a rollout state 12 steps in (contacts made), ONE T = 1 launch of all 2048 envs; 32 sampled envs are re-stepped by the
-    oracle from the same state and action.  C1: cur_frame exact, done exact away from the height thresholds, wrapper steps exact;
+    N = 16): from a rollout state 12 steps in (contacts made), ONE T = 1 launch of all 2048 envs; 512 sampled envs are re-stepped by the
+    oracle from the same state and action (512, not 32: between its median and its 90th percentile the one-step error of the truncated
+    CG 8/8 map spans three decades -- 9e-4 to 2.8 in qvel on the first run -- so the median of 27 samples scatters by a factor of 3).  C1: cur_frame exact, done exact away from the height thresholds, wrapper steps exact;
     C3: every observation segment, qpos, qvel, reward within 3x the scalar float32 oracle's own distance (tests/parity.py)."""
     from rodent_amd import envs, jax_random
     from rodent_amd.envs import wrappers
@@ -302,11 +303,11 @@ def test_timed_instance_at_timed_size_against_the_oracle(oracle_built):
     steps0, done0 = st.info["steps"].cpu().numpy().copy(), st.done.cpu().numpy().copy()
     ns = wenv.unroll(st, a)
     torch.cuda.synchronize()
-    pick = np.random.default_rng(5).choice(N, 32, replace=False)
+    pick = np.random.default_rng(5).choice(N, 512, replace=False)
     sub = {k: v[pick] for k, v in before.items()}
     act = a[0].cpu().numpy().astype(np.float64)[pick]
-    A = parity.OracleEnvImpl("rodent_optimized", 32, "f64", (8, 8), track)
-    B = parity.OracleEnvImpl("rodent_optimized", 32, "f32", (8, 8), track)
+    A = parity.OracleEnvImpl("rodent_optimized", 512, "f64", (8, 8), track)
+    B = parity.OracleEnvImpl("rodent_optimized", 512, "f32", (8, 8), track)
     want, gap = A.env_step(sub, act, cf0[pick]), B.env_step(sub, act, cf0[pick])
     np.testing.assert_array_equal(ns.info["cur_frame"].cpu().numpy()[pick], want["cur_frame"])
     np.testing.assert_array_equal(ns.info["steps"].cpu().numpy()[pick], np.where(done0[pick] != 0, 0.0, steps0[pick]) + 1)
@@ -316,7 +317,7 @@ def test_timed_instance_at_timed_size_against_the_oracle(oracle_built):
     hd = ns.done.cpu().numpy()[pick]
     assert not ((hd != np.where(over, 1.0, want["done"])) & ~near).any()
     keep = hd == 0                                            # envs that were auto-reset carry their first state, not the stepped one
-    assert keep.sum() >= 24
+    assert keep.sum() >= 400
     got_obs = ns.obs.cpu().numpy().astype(np.float64)[pick][keep]
     seg = parity.obs_segments(mjcf_tables("rodent_optimized"))
     rows = []
