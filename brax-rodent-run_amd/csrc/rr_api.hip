@@ -482,6 +482,13 @@ static int launch(rr_batch* b, const rr_state* st, const float* ctrl, int n_fram
     if (b->progress && unroll_T > 1) {
       HIPCHK(hipMemsetAsync(b->progress, 0, 4, b->stream));
       io.progress = b->progress;
+      static const struct Pace { float t[3]; int mode; } pace = [] {        // RR_PACE_T="t1,t2,t3", RR_PACE_MODE: tuning switches (tools/)
+        Pace p = {{0.3f, 0.6f, 1.0f}, 0};
+        if (const char* e = getenv("RR_PACE_T")) sscanf(e, "%f,%f,%f", &p.t[0], &p.t[1], &p.t[2]);
+        if (const char* e = getenv("RR_PACE_MODE")) p.mode = atoi(e);
+        return p;
+      }();
+      io.pace_t1 = pace.t[0]; io.pace_t2 = pace.t[1]; io.pace_t3 = pace.t[2]; io.pace_mode = pace.mode;
     }
   }
   if (!kern) return fail(RR_EUNSUPPORTED, "launch: no diagnostic kernel instance for this model");
@@ -810,14 +817,19 @@ extern "C" int rr_mlp_value_backward(const float* grad_value, const float* head_
 
 // weight gradient dW = delta' h as a split-row matrix-core product (csrc/rr_mlp.h)
 struct DwPlan { int to, ti, kc, rows_per_slice, nslice; };
-static DwPlan dw_plan(int M, int O, int I) {
+// `group_tiles`: output tiles of ALL products that share this product's launch (rr_mlp_weight_grad_batch runs the products of one tile
+// shape as one launch, item = grid z); 0 = the product is launched alone.  The slices are cut so that the LAUNCH has ~target workgroups:
+// planned per product (round 2), the four 256 x 256 hidden-layer products of a minibatch were cut into 128 slices each although their
+// launch already holds 36 tiles -- 134 MB of partial tiles written and read back where 29 MB do.
+static DwPlan dw_plan(int M, int O, int I, int group_tiles = 0) {
   DwPlan p;
   p.to = O <= 32 ? 32 : (O <= 64 ? 64 : 128);
   p.ti = O <= 32 ? 128 : (O <= 64 ? 64 : 128);
   p.kc = O <= 32 ? 64 : (O <= 64 ? 32 : 16);             // equal matrix-core work per LDS hand-off in the three tile shapes
-  const int tiles = ((O + p.to - 1) / p.to) * ((I + p.ti - 1) / p.ti);
+  const int tiles = group_tiles > 0 ? group_tiles : ((O + p.to - 1) / p.to) * ((I + p.ti - 1) / p.ti);
   static const int target = [] { const char* e = getenv("RR_DW_TARGET_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();   // workgroups per product
-  const int want = std::max(1, std::min(target / tiles, M / (2 * p.kc)));
+  static const int target_batch = [] { const char* e = getenv("RR_DW_TARGET_WGS_BATCH"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();   // ... per batched launch: two resident rounds
+  const int want = std::max(1, std::min((group_tiles > 0 ? target_batch : target) / tiles, M / (2 * p.kc)));
   p.rows_per_slice = ((M + want - 1) / want + p.kc - 1) / p.kc * p.kc;
   p.nslice = (M + p.rows_per_slice - 1) / p.rows_per_slice;
   return p;
@@ -838,9 +850,25 @@ static int dw_launch(const RRDwBatch& B, dim3 grid, hipStream_t st) {
   hipLaunchKernelGGL((rr_mlp_dw_kernel<GO, GI, WO, WI, KC>), grid, dim3(256), lds, st, B);
   return RR_OK;
 }
+// tiles of each tile-shape group of a batch (the products of one shape share a launch)
+static void dw_group_tiles(const rr_dw_item* items, int n, int* gt) {
+  gt[0] = gt[1] = gt[2] = 0;
+  for (int i = 0; i < n; ++i) {
+    const DwPlan p = dw_plan(items[i].M, items[i].O, items[i].I);
+    gt[p.to == 32 ? 0 : (p.to == 64 ? 1 : 2)] += ((items[i].O + p.to - 1) / p.to) * ((items[i].I + p.ti - 1) / p.ti);
+  }
+}
+static DwPlan dw_plan_batch(const rr_dw_item& it, const int* gt) {
+  const DwPlan p = dw_plan(it.M, it.O, it.I);
+  return dw_plan(it.M, it.O, it.I, gt[p.to == 32 ? 0 : (p.to == 64 ? 1 : 2)]);
+}
 extern "C" size_t rr_mlp_weight_grad_batch_workspace_bytes(const rr_dw_item* items, int32_t n) {
   size_t t = 0;
-  for (int i = 0; items && i < n; ++i) t += rr_align_up(rr_mlp_weight_grad_workspace_bytes(items[i].M, items[i].O, items[i].I), 256);
+  int gt[3];
+  if (!items || n <= 0) return 0;
+  for (int i = 0; i < n; ++i) if (items[i].M <= 0 || items[i].O <= 0 || items[i].I <= 0) return 0;
+  dw_group_tiles(items, n, gt);
+  for (int i = 0; i < n; ++i) t += rr_align_up((size_t)dw_plan_batch(items[i], gt).nslice * items[i].O * items[i].I * sizeof(float), 256);
   return t;
 }
 extern "C" int rr_mlp_weight_grad_batch(const rr_dw_item* items, int32_t n, void* workspace, size_t workspace_bytes, void* stream) {
@@ -853,25 +881,28 @@ extern "C" int rr_mlp_weight_grad_batch(const rr_dw_item* items, int32_t n, void
   dim3 ggrid[3] = {dim3(0, 0, 0), dim3(0, 0, 0), dim3(0, 0, 0)};
   unsigned red_blocks = 0;
   char* w = (char*)workspace;
+  int gt[3];
+  for (int i = 0; i < n; ++i)
+    if (!items[i].delta || !items[i].act || !items[i].grad || items[i].M <= 0 || items[i].O <= 0 || items[i].I <= 0) return fail(RR_EINVAL, "rr_mlp_weight_grad_batch: bad item");
+  dw_group_tiles(items, n, gt);
   for (int i = 0; i < n; ++i) {
     const rr_dw_item& it = items[i];
-    if (!it.delta || !it.act || !it.grad || it.M <= 0 || it.O <= 0 || it.I <= 0) return fail(RR_EINVAL, "rr_mlp_weight_grad_batch: bad item");
     if ((it.mean == nullptr) != (it.std == nullptr) || (it.mean && !it.delta_colsum))
       return fail(RR_EINVAL, "rr_mlp_weight_grad_batch: mean, std and delta_colsum must be given together");
-    const DwPlan p = dw_plan(it.M, it.O, it.I);
+    const DwPlan p = dw_plan_batch(it, gt);
     RRDwArgs A;
     memset(&A, 0, sizeof(A));
     A.rows_per_slice = p.rows_per_slice; A.nslice = p.nslice;
     A.a = it.delta; A.b = it.act; A.rows = it.act_rows; A.mean = it.mean; A.std_ = it.std; A.bsum = it.delta_colsum; A.M = it.M; A.O = it.O; A.I = it.I;
     A.part = (float*)w; A.out = it.grad;
-    w += rr_align_up(rr_mlp_weight_grad_workspace_bytes(it.M, it.O, it.I), 256);
+    w += rr_align_up((size_t)p.nslice * it.O * it.I * sizeof(float), 256);
     all.it[all.n++] = A;
     const int g = p.to == 32 ? 0 : (p.to == 64 ? 1 : 2);
     grp[g].it[grp[g].n++] = A;
     ggrid[g].x = std::max<unsigned>(ggrid[g].x, ((it.O + p.to - 1) / p.to) * ((it.I + p.ti - 1) / p.ti));
     ggrid[g].y = std::max<unsigned>(ggrid[g].y, (unsigned)p.nslice);
     ggrid[g].z = grp[g].n;
-    red_blocks = std::max<unsigned>(red_blocks, (unsigned)(((size_t)it.O * it.I + 15) / 16));
+    red_blocks = std::max<unsigned>(red_blocks, (unsigned)(((size_t)it.O * it.I + 1023) / 1024));
   }
   hipStream_t st = (hipStream_t)stream;
   int rc = RR_OK;

@@ -171,6 +171,8 @@ struct RRIO {
   // its wave priority (Wave::env_prio): the launch ends when its SLOWEST environment does, and a wave that outranks its SIMD partner
   // runs at close to single-wave speed while the partner, which is ahead, has slack.  Timing only -- results are unaffected.
   unsigned* progress;
+  float pace_t1, pace_t2, pace_t3;   // env steps behind the average for priority levels 1, 2, 3
+  int pace_mode;                     // 0: max(weight level, lag level); 1: lag level only; 2: sum, capped at 3
   int mode;  // 0 = forward only (pipeline_init), 1 = step; bit 1 (2) = env epilogue as reset (obs only)
   int pad_;
 };
@@ -402,6 +404,7 @@ struct Wave {
   int lane;               // re-derived (opaquely) at the head of every substep: see RR_FRAME_LOCAL in the kernel
   float* const lds;
   int rep = 0;            // PAIR: this wave's replica (wave-uniform)
+  int lag_mode = 0;       // how lag_prio combines with the weight-based level (RRIO::pace_mode)
   int lag_prio = 0;       // multi-step launches: priority level of an environment that is behind the launch's average progress (wave-uniform)
   int xpar = 0;           // PAIR: parity of the next exchange (two buffers: a wave may be one exchange ahead of its partner)
   float* s_xc = nullptr;  // PAIR: exchange cells [2 parities][2 waves][8] behind the two replicas' regions
@@ -478,7 +481,9 @@ struct Wave {
 #endif
     // ... raised for an environment that has fallen behind the others of a multi-step launch (lag_prio, set by the kernel per env step)
     const int by_weight = jnact >= 12 ? 3 : (jnact >= 6 ? 2 : (jnact >= 2 ? 1 : 0));
-    const int p = by_weight > lag_prio ? by_weight : lag_prio;
+    int p = by_weight > lag_prio ? by_weight : lag_prio;
+    if (lag_mode == 1) p = lag_prio;                                         // progress only
+    else if (lag_mode == 2) p = by_weight + lag_prio > 3 ? 3 : by_weight + lag_prio;
     if (p >= 3) __builtin_amdgcn_s_setprio(3);          // (s_setprio takes an immediate)
     else if (p == 2) __builtin_amdgcn_s_setprio(2);
     else if (p == 1) __builtin_amdgcn_s_setprio(1);
@@ -2313,7 +2318,8 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * RR_LANES, (NVS >= 3 ? 1 : 2)) void
         if (lane == 0) seen = __hip_atomic_fetch_add(io.progress, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
         seen = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);
         const float behind = (float)seen / (float)num_envs - (float)(ut + 1);      // env steps behind the average environment
-        w.lag_prio = behind > 1.0f ? 3 : (behind > 0.6f ? 2 : (behind > 0.3f ? 1 : 0));
+        w.lag_prio = behind > io.pace_t3 ? 3 : (behind > io.pace_t2 ? 2 : (behind > io.pace_t1 ? 1 : 0));
+        w.lag_mode = io.pace_mode;
       }
       if (ut == nsteps - 1) {
         if (lane == 0) { io.done[env] = done2; io.steps_out[env] = u_steps; io.trunc_out[env] = trunc; }

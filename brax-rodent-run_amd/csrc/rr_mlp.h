@@ -592,29 +592,44 @@ __global__ __launch_bounds__(256, 2) void rr_mlp_dw_kernel(const RRDwBatch B) {
       }
     }
 }
-// out[e] = sum_s part[s][e] (then the normaliser, see RRDwArgs): a block owns 16 consecutive outputs, 16 groups of threads each
-// add every 16th slice, the 16 group sums go through LDS in a fixed order
+// out[e] = sum_s part[s][e] (then the normaliser, see RRDwArgs), slices added in order s = 0, 1, .. (fixed order: graph replay == eager,
+// bit for bit).  A thread owns FOUR consecutive outputs and walks the slices with 16-byte loads, eight in flight: a wave reads 1 KB of
+// one slice per instruction.  (Round 2's form -- a block per 16 outputs, 16 thread groups each adding every 16th slice in 64-byte
+// pieces -- took 101 us per minibatch for ~170 MB of partial tiles; the planner now also cuts fewer slices, see dw_plan_batch.)
 __global__ __launch_bounds__(256) void rr_mlp_dw_reduce_kernel(const RRDwBatch B) {
-  __shared__ float sh[256];
   const RRDwArgs& A = B.it[blockIdx.y];
   const size_t n = (size_t)A.O * A.I;
-  if ((size_t)blockIdx.x * 16 >= n) return;          // uniform: past this item's outputs
-  const int c = threadIdx.x & 15, sg = threadIdx.x >> 4;
-  const size_t e = (size_t)blockIdx.x * 16 + c;
-  float t = 0.0f;
-  if (e < n)
-    for (int s = sg; s < A.nslice; s += 16) t += A.part[(size_t)s * n + e];
-  sh[threadIdx.x] = t;
-  __syncthreads();
-  if (sg == 0 && e < n) {
-    float u = 0.0f;
+  const size_t e0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e0 >= n) return;
+  float u[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  const int ns = A.nslice;
+  if ((n & 3) == 0) {                       // every slice starts 16-byte aligned
+    const float* p = A.part + e0;
+    int s = 0;
+    for (; s + 8 <= ns; s += 8) {
+      rr_f4 v[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) u += sh[r * 16 + c];
-    if (A.mean) {
-      const int o = (int)(e / A.I), i = (int)(e % A.I);
-      u = (u - A.bsum[o] * A.mean[i]) / A.std_[i];
+      for (int j = 0; j < 8; ++j) v[j] = *(const rr_f4*)(p + (size_t)(s + j) * n);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { u[0] += v[j][0]; u[1] += v[j][1]; u[2] += v[j][2]; u[3] += v[j][3]; }
     }
-    A.out[e] = u;
+    for (; s < ns; ++s) { const rr_f4 v = *(const rr_f4*)(p + (size_t)s * n); u[0] += v[0]; u[1] += v[1]; u[2] += v[2]; u[3] += v[3]; }
+  } else {
+    for (int s = 0; s < ns; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (e0 + j < n) u[j] += A.part[(size_t)s * n + e0 + j];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const size_t e = e0 + j;
+    if (e < n) {
+      float r = u[j];
+      if (A.mean) {
+        const int o = (int)(e / A.I), i = (int)(e % A.I);
+        r = (r - A.bsum[o] * A.mean[i]) / A.std_[i];
+      }
+      A.out[e] = r;
+    }
   }
 }
 
