@@ -834,9 +834,13 @@ static DwPlan dw_plan(int M, int O, int I, int group_tiles = 0) {
   p.nslice = (M + p.rows_per_slice - 1) / p.rows_per_slice;
   return p;
 }
-extern "C" size_t rr_mlp_weight_grad_workspace_bytes(int32_t M, int32_t O, int32_t I) {
+extern "C" size_t rr_mlp_weight_grad_batch_workspace_bytes(const rr_dw_item* items, int32_t n);
+extern "C" size_t rr_mlp_weight_grad_workspace_bytes(int32_t M, int32_t O, int32_t I) {      // a single product = a batch of one
   if (M <= 0 || O <= 0 || I <= 0) return 0;
-  return (size_t)dw_plan(M, O, I).nslice * O * I * sizeof(float);
+  rr_dw_item it;
+  memset(&it, 0, sizeof(it));
+  it.M = M; it.O = O; it.I = I;
+  return rr_mlp_weight_grad_batch_workspace_bytes(&it, 1);
 }
 template <int GO, int GI, int WO, int WI, int KC>
 static int dw_launch(const RRDwBatch& B, dim3 grid, hipStream_t st) {
@@ -924,6 +928,36 @@ extern "C" int rr_mlp_weight_grad(const float* delta, const float* act, const in
   it.delta = delta; it.act = act; it.act_rows = act_rows; it.mean = mean; it.std = std_; it.delta_colsum = delta_colsum; it.M = M; it.O = O; it.I = I;
   it.grad = grad;
   return rr_mlp_weight_grad_batch(&it, 1, workspace, rr_align_up(workspace_bytes, 256), stream);
+}
+
+// ------------------------------------------------------------------------------------------ observation normaliser sums (csrc/rr_ppo.h)
+static void mom_plan(long long nrows, int* rows_per_block, int* nblk) {
+  const long long target = 2048;                              // blocks: one resident round of 8 per CU
+  long long rpb = (nrows + target - 1) / target;
+  if (rpb < 16) rpb = 16;
+  *rows_per_block = (int)rpb;
+  *nblk = (int)((nrows + rpb - 1) / rpb);
+}
+extern "C" size_t rr_obs_moments_workspace_bytes(int64_t nseq, int32_t T, int32_t K) {
+  if (nseq <= 0 || T <= 0 || K <= 0) return 0;
+  int rpb, nblk;
+  mom_plan((long long)nseq * T, &rpb, &nblk);
+  return (size_t)nblk * 2 * K * sizeof(double);
+}
+extern "C" int rr_obs_moments(const float* obs, int64_t nseq, int32_t Tp1, int32_t T, int32_t K, const float* mean, double* sums, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  if (!obs || !mean || !sums || !workspace || nseq <= 0 || T <= 0 || Tp1 < T || K <= 0) return fail(RR_EINVAL, "rr_obs_moments: bad argument");
+  if (workspace_bytes < rr_obs_moments_workspace_bytes(nseq, T, K) || ((uintptr_t)workspace & 7) || ((uintptr_t)sums & 7))
+    return fail(RR_EINVAL, "rr_obs_moments: workspace too small (rr_obs_moments_workspace_bytes) or not 8-byte aligned");
+  RRMomArgs A;
+  memset(&A, 0, sizeof(A));
+  A.obs = obs; A.mean = mean; A.nrows = (long long)nseq * T; A.Tp1 = Tp1; A.T = T; A.K = K; A.part = (double*)workspace; A.out = sums;
+  mom_plan(A.nrows, &A.rows_per_block, &A.nblk);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(rr_obs_moments_kernel, dim3(A.nblk), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(rr_obs_moments_reduce_kernel, dim3((2 * K + 255) / 256), dim3(256), 0, st, A);
+  HIPCHK(hipGetLastError());
+  return RR_OK;
 }
 
 // ------------------------------------------------------------------------------------------ training wrappers, fused

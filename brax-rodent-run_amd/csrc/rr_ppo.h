@@ -398,3 +398,45 @@ __global__ __launch_bounds__(256) void rr_policy_tail_kernel(const RRPolTailArgs
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------ observation normaliser: the update's sums
+// brax.training.acme.running_statistics.update [UP; SURVEY.md a24, App. E] needs, per observation column, S1 = sum_x (x - mean_old)
+// and sum_x (x - mean_old)(x - mean_new) over all transitions of a training step (1.3 M rows x 1263 columns = 6.6 GB at the launcher's
+// sizes).  With d = mean_new - mean_old the second sum is S2 - d S1, S2 = sum_x (x - mean_old)^2, so ONE pass over the observations
+// yields both (the tensor-expression form made two 6.6 GB temporaries and ~10 elementwise / reduction passes per training step).
+// The rows are addressed inside the unroll buffer [nseq][Tp1][K]: the first T of every Tp1 rows (the bootstrap row is not a transition).
+// Block b sums its rows for all K columns in double (thread = column, coalesced 4-byte reads across the columns); a second launch adds the
+// block partials in order (fixed order: deterministic, no atomics).
+struct RRMomArgs {
+  const float* obs; const float* mean;
+  long long nrows;          // nseq * T transitions
+  int Tp1, T, K, rows_per_block, nblk;
+  double* part;             // [nblk][2][K]
+  double* out;              // [2][K]: S1 | S2
+};
+__global__ __launch_bounds__(256) void rr_obs_moments_kernel(const RRMomArgs A) {
+  const long long r0 = (long long)blockIdx.x * A.rows_per_block;
+  const long long r1 = r0 + A.rows_per_block < A.nrows ? r0 + A.rows_per_block : A.nrows;
+  for (int k = threadIdx.x; k < A.K; k += 256) {
+    const float m = A.mean[k];
+    double s1 = 0.0, s2 = 0.0;
+    long long seq = r0 / A.T;
+    int t = (int)(r0 - seq * A.T);
+    const float* p = A.obs + ((size_t)seq * A.Tp1 + t) * A.K + k;
+    for (long long r = r0; r < r1; ++r) {
+      const float d = *p - m;
+      s1 += (double)d;
+      s2 += (double)d * (double)d;
+      if (++t == A.T) { t = 0; p += (size_t)(A.Tp1 - A.T + 1) * A.K; } else p += A.K;
+    }
+    A.part[((size_t)blockIdx.x * 2) * A.K + k] = s1;
+    A.part[((size_t)blockIdx.x * 2 + 1) * A.K + k] = s2;
+  }
+}
+__global__ __launch_bounds__(256) void rr_obs_moments_reduce_kernel(const RRMomArgs A) {
+  const int e = blockIdx.x * 256 + threadIdx.x;        // 0 .. 2K-1
+  if (e >= 2 * A.K) return;
+  double s = 0.0;
+  for (int b = 0; b < A.nblk; ++b) s += A.part[(size_t)b * 2 * A.K + e];
+  A.out[e] = s;
+}

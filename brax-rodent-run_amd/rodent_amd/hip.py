@@ -65,7 +65,7 @@ class RRPpoCfg(C.Structure):
 
 EXPORTS = ["rr_model_load", "rr_model_dims", "rr_model_set_solver", "rr_model_set_solver_type", "rr_model_destroy", "rr_model_table", "rr_kernarg_layout", "rr_batch_create",
            "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset", "rr_pipeline_step_to", "rr_env_step_to", "rr_batch_unroll_supported", "rr_env_unroll", "rr_env_unroll_policy",
-           "rr_compute_gae", "rr_mlp_forward", "rr_ppo_loss_workspace_bytes", "rr_ppo_loss", "rr_policy_act_workspace_bytes", "rr_policy_act", "rr_policy_sample", "rr_policy_backward_workspace_bytes", "rr_policy_backward", "rr_mlp_silu_backward_workspace_bytes", "rr_mlp_silu_backward", "rr_mlp_value_backward_workspace_bytes", "rr_mlp_value_backward", "rr_mlp_weight_grad_workspace_bytes", "rr_mlp_weight_grad", "rr_mlp_weight_grad_batch_workspace_bytes", "rr_mlp_weight_grad_batch", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_schedule", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
+           "rr_compute_gae", "rr_mlp_forward", "rr_ppo_loss_workspace_bytes", "rr_ppo_loss", "rr_policy_act_workspace_bytes", "rr_policy_act", "rr_policy_sample", "rr_policy_backward_workspace_bytes", "rr_policy_backward", "rr_mlp_silu_backward_workspace_bytes", "rr_mlp_silu_backward", "rr_mlp_value_backward_workspace_bytes", "rr_mlp_value_backward", "rr_mlp_weight_grad_workspace_bytes", "rr_mlp_weight_grad", "rr_mlp_weight_grad_batch_workspace_bytes", "rr_mlp_weight_grad_batch", "rr_obs_moments_workspace_bytes", "rr_obs_moments", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_schedule", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
 
 _lib = None
 
@@ -134,6 +134,9 @@ def lib():
         L.rr_mlp_weight_grad_batch.argtypes = [C.POINTER(RRDwItem), C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]
         L.rr_wrap_episode_autoreset.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32)] + \
             [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_void_p]
+        L.rr_obs_moments_workspace_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
+        L.rr_obs_moments_workspace_bytes.restype = C.c_size_t
+        L.rr_obs_moments.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.rr_batch_set_profile.argtypes = [C.c_void_p, C.c_void_p]
         L.rr_batch_set_schedule.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.rr_batch_set_timing.argtypes = [C.c_void_p, C.c_int32]
@@ -541,6 +544,23 @@ def mlp_weight_grad(delta, act, out, rows=None, mean=None, std=None, delta_colsu
                                     _ptr(mean, numel=I) if mean is not None else None, _ptr(std, numel=I) if std is not None else None,
                                     _ptr(delta_colsum, numel=O) if mean is not None else None, M, O, I, out.data_ptr(), ws.data_ptr(), ws.numel() * 4, C.c_void_p(torch.cuda.current_stream(delta.device).cuda_stream)))
     return out
+
+
+def obs_moments(obs, T: int, mean, bufs=None):
+    """S1 = sum (x - mean), S2 = sum (x - mean)^2 per observation column (float64 [2, K]) over the rows t < T of every sequence of
+    `obs` [..., Tp1, K] (contiguous float32 device tensor; C ABI `rr_obs_moments`): the normaliser update's sums in one pass."""
+    K, Tp1 = obs.shape[-1], obs.shape[-2]
+    nseq = obs.numel() // (Tp1 * K)
+    _ptr(obs); _ptr(mean, numel=K)
+    nb = lib().rr_obs_moments_workspace_bytes(nseq, T, K)
+    bufs = {} if bufs is None else bufs
+    ws = bufs.get("mom_ws")
+    if ws is None or ws.numel() * 8 < nb or ws.device != obs.device:
+        ws = bufs["mom_ws"] = torch.empty((nb + 7) // 8, dtype=torch.float64, device=obs.device)
+    sums = torch.empty(2, K, dtype=torch.float64, device=obs.device)
+    _check(lib().rr_obs_moments(obs.data_ptr(), nseq, Tp1, T, K, mean.data_ptr(), sums.data_ptr(), ws.data_ptr(), ws.numel() * 8,
+                                C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)))
+    return sums
 
 
 def policy_sample(logits, noise, min_std: float):

@@ -295,7 +295,7 @@ def train(
         t1 = time.time()
         data = buf.flat()
         if normalize_observations:                       # update on `observation` (not next_observation), all ranks
-            normalizer_params = running_statistics.update(normalizer_params, buf.obs[:, :, :T])
+            normalizer_params = running_statistics.update_from_unroll_buffer(normalizer_params, buf.obs, T)
         metrics = {}
         if normalize_observations and gstate["norm"] is not None:     # the graph reads the normaliser from fixed buffers
             for f in ("count", "mean", "summed_variance", "std"):

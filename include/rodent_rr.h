@@ -300,6 +300,17 @@ typedef struct rr_dw_item {
 size_t rr_mlp_weight_grad_batch_workspace_bytes(const rr_dw_item* items, int32_t n);
 int rr_mlp_weight_grad_batch(const rr_dw_item* items, int32_t n, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The sums of the observation normaliser's update, brax.training.acme.running_statistics.update [UP; SURVEY.md a24, Appendix E;
+ * normalize_observations=True in REF brax_rodent_run_ppo.py:103], in one pass over the transitions of a training step: per observation
+ * column k,  sums[k] = sum_x (x_k - mean_k)  and  sums[K + k] = sum_x (x_k - mean_k)^2  (double), over the rows t < T of every
+ * sequence of `obs` [nseq][Tp1][K] (the unroll buffer: row T of a sequence is the bootstrap observation, not a transition; Tp1 = T for
+ * a plain [rows][K] batch).  The update then is  mean' = mean + S1 / count',  summed_variance += S2 - (mean' - mean) S1  -- what upstream
+ * forms as sum (x - mean)(x - mean') -- with S1, S2 all-reduced over the ranks.  Fixed-order reductions, no atomics.
+ * workspace: rr_obs_moments_workspace_bytes(nseq, T, K) bytes of device memory, 8-byte aligned; sums: device double [2 K]. */
+size_t rr_obs_moments_workspace_bytes(int64_t nseq, int32_t T, int32_t K);
+int rr_obs_moments(const float* obs, int64_t nseq, int32_t Tp1, int32_t T, int32_t K, const float* mean, double* sums, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
 /* brax.envs.wrappers.training.EpisodeWrapper + AutoResetWrapper [UP; SURVEY.md 3.4] after an env step, in one launch:
  * steps' = (prev_done ? 0 : prev_steps) + action_repeat; over = steps' >= episode_length; done <- over ? 1 : done;
  * truncation = over ? 1 - done_env : 0; and for every env with done != 0 the rows of the `narr` (<= 12) arrays `cur[i]`

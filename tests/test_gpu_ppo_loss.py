@@ -340,3 +340,26 @@ def test_weight_grad_batch_equals_single_calls():
     torch.cuda.synchronize()
     for s1, it in zip(single, items):
         assert torch.isfinite(s1).all() and torch.equal(s1, it["out"])
+
+
+def test_obs_moments_kernel_against_numpy():
+    """`rr_obs_moments` (the normaliser update's sums in one pass over the unroll buffer) against float64 numpy: rows
+    t < T of every sequence only, odd widths, more rows than one block; and the resulting update against the tensor-expression form."""
+    from rodent_amd import hip
+    from rodent_amd.training import running_statistics
+    rng = np.random.default_rng(0)
+    for shape, T in (((3, 50, 11, 37), 10), ((2, 700, 6, 1263), 5), ((1, 9, 4, 5), 4)):
+        x = rng.normal(0.7, 1.9, size=shape).astype(np.float32)
+        mean = rng.normal(0.5, 0.3, size=shape[-1]).astype(np.float32)
+        got = hip.obs_moments(torch.tensor(x, device=DEV), T, torch.tensor(mean, device=DEV)).cpu().numpy()
+        d = x[..., :T, :].astype(np.float64).reshape(-1, shape[-1]) - mean.astype(np.float64)
+        np.testing.assert_allclose(got[0], d.sum(0), rtol=1e-12, atol=1e-9)
+        np.testing.assert_allclose(got[1], (d * d).sum(0), rtol=1e-12, atol=1e-9)
+    st = running_statistics.init_state(37, DEV)
+    ref = running_statistics.init_state(37, DEV)
+    for i in range(3):
+        buf = torch.tensor(rng.normal(1.0 + i, 2.0, size=(4, 64, 11, 37)).astype(np.float32), device=DEV)
+        st = running_statistics.update_from_unroll_buffer(st, buf, 10)
+        ref = running_statistics.update(ref, buf[:, :, :10])
+        for f in ("count", "mean", "summed_variance", "std"):
+            torch.testing.assert_close(getattr(st, f), getattr(ref, f), rtol=3e-5, atol=1e-5)

@@ -202,3 +202,23 @@ def test_actor_params_layout_of_the_in_kernel_policy():
     logits = (h @ a["head_wt"] + a["head_b"])[:, :2 * A]
     want = net((x - norm.mean) / norm.std)
     assert torch.allclose(logits, want, atol=1e-5) and float((h @ a["head_wt"] + a["head_b"])[:, 2 * A:].abs().max()) == 0.0
+
+
+def test_running_statistics_from_sums_equals_the_upstream_form():
+    """`update_from_sums` (S1, S2 of the batch about the OLD mean; what the one-pass GPU kernel rr_obs_moments delivers) against
+    `update` (the upstream formulation: sum (x - mean_old)(x - mean_new)), over several successive updates."""
+    rng = np.random.default_rng(3)
+    a = running_statistics.init_state(5, "cpu")
+    b = running_statistics.init_state(5, "cpu")
+    for i in range(4):
+        x = torch.tensor(rng.normal(1.5, 2.0, size=(7, 11, 5)), dtype=torch.float32)
+        a = running_statistics.update(a, x)
+        d = x.reshape(-1, 5).double() - b.mean.double()
+        b = running_statistics.update_from_sums(b, d.shape[0], torch.stack([d.sum(0), (d * d).sum(0)]))
+        for f in ("count", "mean", "summed_variance", "std"):
+            torch.testing.assert_close(getattr(a, f), getattr(b, f), rtol=2e-5, atol=1e-6)
+    # CPU path of the unroll-buffer entry point = the generic update on the first T rows of every sequence
+    buf = torch.tensor(rng.normal(size=(3, 4, 6, 5)), dtype=torch.float32)
+    c = running_statistics.update_from_unroll_buffer(a, buf, 5)
+    d_ = running_statistics.update(a, buf[:, :, :5])
+    torch.testing.assert_close(c.mean, d_.mean); torch.testing.assert_close(c.std, d_.std)

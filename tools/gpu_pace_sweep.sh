@@ -5,9 +5,9 @@ for rep in 1 2; do
 run RR_PACE=0
 run RR_PACE_T=0.3,0.6,1.0 RR_PACE_MODE=0
 run RR_PACE_T=0.1,0.3,0.6 RR_PACE_MODE=0
-run RR_PACE_T=0.05,0.15,0.4 RR_PACE_MODE=0
-run RR_PACE_T=-0.1,0.1,0.4 RR_PACE_MODE=1
-run RR_PACE_T=-0.2,0.0,0.3 RR_PACE_MODE=1
-run RR_PACE_T=0.1,0.3,0.6 RR_PACE_MODE=2
-run RR_PACE_T=0.05,0.2,0.5 RR_PACE_MODE=2
+run RR_PACE_T=0.5,1.0,1.5 RR_PACE_MODE=0
+run RR_PACE_T=0.4,0.8,1.2 RR_PACE_MODE=0
+run RR_PACE_T=0.7,1.2,2.0 RR_PACE_MODE=0
+run RR_PACE_T=0.3,0.5,0.8 RR_PACE_MODE=0
+run RR_PACE_T=0.2,0.6,1.2 RR_PACE_MODE=0
 done
