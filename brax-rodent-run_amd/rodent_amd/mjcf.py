@@ -577,7 +577,7 @@ def compile_mjcf(xml_path: str, *, iterations: int = 6, ls_iterations: int = 6,
     # the fused HIP kernel serves the floor-contact, joint-actuated, free-floating rodents; other models (rodent_cpu.xml:
     # tendon transmissions, welded root) compile for the CPU path only and their blob carries no kernel tables, so
     # rr_model_load refuses them
-    hip_ok = (not any(trn_type)) and int(m["ncon"]) > 0 and any(t == FREE for t in jnt_type)
+    hip_ok = (not any(trn_type)) and int(m["ncon"]) > 0 and any(t == FREE for t in jnt_type) and not np.any(m["con_body1"] != 0) and not np.any(m["con_dim"] != 3)
     m["hip_supported"] = np.int32(hip_ok)
     if hip_ok:
         from .ktables import build_kernel_tables, replica_model
@@ -740,14 +740,17 @@ def _collision_tables(m, contacts="strict"):
                 continue
             pairs.append((int(t1), int(t2), a, b))
     pairs.sort()
-    ok = [p for p in pairs if p[0] == PLANE and p[1] in (SPHERE, CAPSULE, ELLIPSOID)]
+    # supported primitives [UP mjx collision_primitive]: plane - sphere / capsule / ellipsoid (the floor contacts of the rodent models) and,
+    # SURVEY.md 8(f)-4, the sphere / capsule pairs of self-colliding models (rodent_cpu.xml): sphere-sphere, sphere-capsule, capsule-capsule
+    ok = [p for p in pairs if (p[0] == PLANE and p[1] in (SPHERE, CAPSULE, ELLIPSOID)) or (p[0] in (SPHERE, CAPSULE) and p[1] in (SPHERE, CAPSULE))]
     m["ndropped_pairs"] = np.int32(len(pairs) - len(ok))
     if len(ok) != len(pairs):
         if contacts != "supported_only":
             t1, t2 = next((p[0], p[1]) for p in pairs if p not in ok)
             raise ValueError(f"collision type pair ({t1},{t2}) not supported (plane-sphere/capsule/ellipsoid only)")
         pairs = ok
-    con_geom1, con_geom2, con_kind = [], [], []   # kind: 0 sphere, 1 capsule +axis end, 2 capsule -axis end, 3 ellipsoid
+    # kind: 0 plane-sphere, 1 / 2 plane-capsule +axis / -axis end, 3 plane-ellipsoid, 4 sphere-sphere, 5 sphere-capsule, 6 capsule-capsule
+    con_geom1, con_geom2, con_kind, con_dim = [], [], [], []
     fr, sr, si = [], [], []
     for t1, t2, g1, g2 in pairs:
         p1, p2 = m["geom_priority"][g1], m["geom_priority"][g2]
@@ -760,31 +763,32 @@ def _collision_tables(m, contacts="strict"):
         else:
             gp = g1 if p1 > p2 else g2
             f, s_ref, s_imp, cd = m["geom_friction"][gp], m["geom_solref"][gp], m["geom_solimp"][gp], m["geom_condim"][gp]
-        if cd != 3:
-            raise ValueError("only condim 3 contacts are supported")
+        if cd not in (1, 3):
+            raise ValueError("only condim 1 (frictionless) and condim 3 contacts are supported")
         if max(m["geom_margin"][g1], m["geom_margin"][g2]) != 0 or max(m["geom_gap"][g1], m["geom_gap"][g2]) != 0:
             raise ValueError("margin / gap not supported")
-        kinds = {SPHERE: [0], CAPSULE: [1, 2], ELLIPSOID: [3]}[t2]
+        kinds = {SPHERE: [0], CAPSULE: [1, 2], ELLIPSOID: [3]}[t2] if t1 == PLANE else [{(SPHERE, SPHERE): 4, (SPHERE, CAPSULE): 5, (CAPSULE, CAPSULE): 6}[(t1, t2)]]
         for k in kinds:
-            con_geom1.append(g1); con_geom2.append(g2); con_kind.append(k)
+            con_geom1.append(g1); con_geom2.append(g2); con_kind.append(k); con_dim.append(int(cd))
             fr.append([f[0], f[0], f[1], f[2], f[2]]); sr.append(s_ref); si.append(s_imp)
     ncon = len(con_geom1)
     m["ncon"] = np.int32(ncon)
     m["con_geom1"] = np.asarray(con_geom1, np.int32).reshape(ncon)
     m["con_geom2"] = np.asarray(con_geom2, np.int32).reshape(ncon)
     m["con_kind"] = np.asarray(con_kind, np.int32).reshape(ncon)
+    m["con_dim"] = np.asarray(con_dim, np.int32).reshape(ncon)      # condim: 3 = pyramid of 4 rows, 1 = frictionless, one normal row
     m["con_friction"] = np.asarray(fr, np.float64).reshape(ncon, 5)
     m["con_solref"] = np.asarray(sr, np.float64).reshape(ncon, 2)
     m["con_solimp"] = np.asarray(si, np.float64).reshape(ncon, 5)
     b1 = gb[m["con_geom1"]] if ncon else np.zeros(0, np.int32)
     b2 = gb[m["con_geom2"]] if ncon else np.zeros(0, np.int32)
     m["con_body1"], m["con_body2"] = b1.astype(np.int32), b2.astype(np.int32)
-    if ncon and np.any(b1 != 0):
-        raise ValueError("contacts must be against a world-body plane")
+    # contacts between two moving bodies (kinds 4-6): J = J(body2) - J(body1); the CPU oracles take them, the HIP kernel's
+    # J-free products walk ONE ancestor chain per contact (floor contacts), so such models get no kernel tables (hip_supported = 0)
     m["con_invweight"] = (m["body_invweight0"][b1, 0] + m["body_invweight0"][b2, 0]) if ncon else np.zeros(0)
     nlim = int(np.sum(m["jnt_limited"]))
     m["nlimit"] = np.int32(nlim)
-    m["nefc"] = np.int32(nlim + 4 * ncon)
+    m["nefc"] = np.int32(nlim + sum(4 if c == 3 else 1 for c in con_dim))
 
 
 # ----------------------------------------------------------------------------- engine tables

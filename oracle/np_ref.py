@@ -248,12 +248,60 @@ def _make_frame_default(n):
     return y / np.linalg.norm(y)
 
 
+def _make_frame(n):
+    b = _make_frame_default(n)
+    return np.stack([n, b, np.cross(n, b)])
+
+
+def _segment_point(a, b, pt):
+    """[UP mjx math.closest_segment_point]"""
+    ab = b - a
+    return a + np.clip((pt - a) @ ab / (ab @ ab + 1e-6), 0.0, 1.0) * ab
+
+
+def _segment_segment(a0, a1, b0, b1):
+    """[UP mjx math.closest_segment_to_segment_points] -- restated with the segments as (mid-point, unit direction, half length)"""
+    la, lb = np.linalg.norm(a1 - a0), np.linalg.norm(b1 - b0)
+    ua, ub = (a1 - a0) / la, (b1 - b0) / lb
+    am, bm = 0.5 * (a0 + a1), 0.5 * (b0 + b1)
+    tr = am - bm
+    c = ua @ ub
+    ta = (-(ua @ tr) + c * (ub @ tr)) / (1 - c * c + 1e-6)
+    tb = ub @ tr + ta * c
+    pa = am + ua * np.clip(ta, -0.5 * la, 0.5 * la)
+    pb = bm + ub * np.clip(tb, -0.5 * lb, 0.5 * lb)
+    na, nb = _segment_point(a0, a1, pb), _segment_point(b0, b1, pa)
+    if (na - pb) @ (na - pb) < (nb - pa) @ (nb - pa):
+        return na, pb
+    return pa, nb
+
+
+def _two_spheres(p1, r1, p2, r2):
+    """[UP mjx collision_primitive._sphere_sphere]"""
+    v = p2 - p1
+    ln = np.linalg.norm(v)
+    n = v / ln if ln > 0 else np.array([1.0, 0.0, 0.0])
+    dist = ln - (r1 + r2)
+    return dist, p1 + n * (r1 + 0.5 * dist), _make_frame(n)
+
+
 def collision(m: Model, d: Data):
-    """plane-sphere / plane-capsule end caps / plane-ellipsoid; kinds as in the blob's con_kind."""
+    """plane-sphere / plane-capsule end caps / plane-ellipsoid, and (8(f)-4) sphere-sphere / sphere-capsule /
+    capsule-capsule between two moving bodies; kinds as in the blob's con_kind."""
     t, nc = m.t, m.ncon
     d.con_dist = np.zeros(nc); d.con_pos = np.zeros((nc, 3)); d.con_frame = np.zeros((nc, 3, 3))
     for c in range(nc):
         g1, g2, kind = t["con_geom1"][c], t["con_geom2"][c], t["con_kind"][c]
+        if kind >= 4:
+            P1, P2, s1, s2 = d.geom_xpos[g1], d.geom_xpos[g2], t["geom_size"][g1], t["geom_size"][g2]
+            ax1, ax2 = d.geom_xmat[g1][:, 2], d.geom_xmat[g2][:, 2]
+            a, b = P1, P2
+            if kind == 5:
+                b = _segment_point(P2 - ax2 * s2[1], P2 + ax2 * s2[1], P1)
+            elif kind == 6:
+                a, b = _segment_segment(P1 - ax1 * s1[1], P1 + ax1 * s1[1], P2 - ax2 * s2[1], P2 + ax2 * s2[1])
+            d.con_dist[c], d.con_pos[c], d.con_frame[c] = _two_spheres(a, s1[0], b, s2[0])
+            continue
         n = d.geom_xmat[g1][:, 2]
         pp = d.geom_xpos[g1]
         G, gp, size = d.geom_xmat[g2], d.geom_xpos[g2], t["geom_size"][g2]
@@ -319,11 +367,16 @@ def make_constraint(m: Model, d: Data):
     for c in range(m.ncon):
         body, dist = t["con_body2"][c], d.con_dist[c]
         mu = t["con_friction"][c, 0]
-        Jc = d.con_frame[c] @ point_jac(m, d, body, d.con_pos[c]) if dist < 0 else np.zeros((3, nv))    # body1 is the world
+        Jc = np.zeros((3, nv))
+        if dist < 0:       # J = jac(body2, pos) - jac(body1, pos); body1 = world for the floor contacts
+            Jc = d.con_frame[c] @ point_jac(m, d, body, d.con_pos[c])
+            if t["con_body1"][c] > 0:
+                Jc = Jc - d.con_frame[c] @ point_jac(m, d, t["con_body1"][c], d.con_pos[c])
         k, b, imp = _kbi(m, t["con_solref"][c], t["con_solimp"][c], dist)
-        invw = (t["con_invweight"][c] + mu * mu * t["con_invweight"][c]) * 2 * mu * mu / m.impratio
+        frictionless = int(t["con_dim"][c]) == 1 if "con_dim" in t else False         # condim 1: one row along the normal
+        invw = t["con_invweight"][c] if frictionless else (t["con_invweight"][c] + mu * mu * t["con_invweight"][c]) * 2 * mu * mu / m.impratio
         r = max(invw * (1 - imp) / imp, MINVAL)
-        for row in (Jc[0] + mu * Jc[1], Jc[0] - mu * Jc[1], Jc[0] + mu * Jc[2], Jc[0] - mu * Jc[2]):
+        for row in ((Jc[0],) if frictionless else (Jc[0] + mu * Jc[1], Jc[0] - mu * Jc[1], Jc[0] + mu * Jc[2], Jc[0] - mu * Jc[2])):
             J.append(row); D.append(1 / r); aref.append(-b * (row @ d.qvel) - k * imp * dist); pos_.append(dist)
     d.efc_J, d.efc_D, d.efc_aref, d.efc_pos = np.array(J), np.array(D), np.array(aref), np.array(pos_)
 

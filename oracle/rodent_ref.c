@@ -49,7 +49,8 @@ typedef double real;
 #define MINIMP R(0.0001)
 #define MAXIMP R(0.9999)
 enum { JNT_FREE = 0, JNT_HINGE = 3 };
-enum { CON_SPHERE = 0, CON_CAP_POS = 1, CON_CAP_NEG = 2, CON_ELLIPSOID = 3 };
+/* con_kind (rodent_amd/mjcf.py _collision_tables): plane - sphere / capsule end / ellipsoid, then the pairs of two moving geoms */
+enum { CON_SPHERE = 0, CON_CAP_POS = 1, CON_CAP_NEG = 2, CON_ELLIPSOID = 3, CON_SPHERE_SPHERE = 4, CON_SPHERE_CAPSULE = 5, CON_CAPSULE_CAPSULE = 6 };
 
 /* ------------------------------------------------------------------ model blob */
 typedef struct {
@@ -71,7 +72,7 @@ typedef struct ref_model {
   const int32_t *body_parentid, *body_rootid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum, *body_lastdof;
   const int32_t *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited;
   const int32_t *dof_bodyid, *dof_jntid, *dof_parentid, *dof_Madr, *dof_depth;
-  const int32_t *geom_bodyid, *con_geom1, *con_geom2, *con_kind, *con_body2, *limit_jnt;
+  const int32_t *geom_bodyid, *con_geom1, *con_geom2, *con_kind, *con_dim, *con_body1, *con_body2, *limit_jnt;
   const int32_t *actuator_qposadr, *actuator_dofadr;
   const int32_t *actuator_momentadr, *actuator_moment_qposadr, *actuator_moment_dofadr; /* sparse transmission (joint: 1 entry, fixed tendon: its joints) */
   /* real tables (converted copies) */
@@ -147,7 +148,7 @@ ref_model* ref_model_load(const char* path) {
   IT(body_parentid); IT(body_rootid); IT(body_jntadr); IT(body_jntnum); IT(body_dofadr); IT(body_dofnum); IT(body_lastdof);
   IT(jnt_type); IT(jnt_qposadr); IT(jnt_dofadr); IT(jnt_bodyid); IT(jnt_limited);
   IT(dof_bodyid); IT(dof_jntid); IT(dof_parentid); IT(dof_Madr); IT(dof_depth);
-  IT(geom_bodyid); IT(con_geom1); IT(con_geom2); IT(con_kind); IT(con_body2); IT(limit_jnt);
+  IT(geom_bodyid); IT(con_geom1); IT(con_geom2); IT(con_kind); IT(con_dim); IT(con_body1); IT(con_body2); IT(limit_jnt);
   IT(actuator_qposadr); IT(actuator_dofadr);
   IT(actuator_momentadr); IT(actuator_moment_qposadr); IT(actuator_moment_dofadr);
 #define RT(x) m->x = rtab(m, #x)
@@ -488,9 +489,80 @@ static void mul_m(const ref_model* m, const real* qM, real* res, const real* v) 
 }
 
 /* ------------------------------------------------------------------ A-4 collision [UP mjx collision_driver / collision_primitive] */
+/* closest point of segment [a, b] to pt  [UP mjx math.closest_segment_point: t = (pt - a).ab / (ab.ab + 1e-6), clipped to [0, 1]] */
+static void closest_segment_point(real* out, const real* a, const real* b, const real* pt) {
+  real ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, pa[3] = {pt[0] - a[0], pt[1] - a[1], pt[2] - a[2]};
+  real t = dot3(pa, ab) / (dot3(ab, ab) + R(1e-6));
+  t = FMIN(FMAX(t, 0), 1);
+  for (int k = 0; k < 3; k++) out[k] = a[k] + t * ab[k];
+}
+/* closest points of two segments  [UP mjx math.closest_segment_to_segment_points]: closest points of the two LINES (parametrised from the
+ * segment mid-points, denominator + 1e-6), clipped to the segments; then the case where both were clipped is resolved by re-projecting
+ * each clipped point on the other segment and keeping the closer pair. */
+static void closest_segment_to_segment(real* best_a, real* best_b, const real* a0, const real* a1, const real* b0, const real* b1) {
+  real da[3], db[3], amid[3], bmid[3], trans[3];
+  real la = 0, lb = 0;
+  for (int k = 0; k < 3; k++) { da[k] = a1[k] - a0[k]; db[k] = b1[k] - b0[k]; la += da[k] * da[k]; lb += db[k] * db[k]; }
+  la = SQRT(la); lb = SQRT(lb);
+  for (int k = 0; k < 3; k++) { da[k] = la > 0 ? da[k] / la : 0; db[k] = lb > 0 ? db[k] / lb : 0; }
+  real ha = la * R(0.5), hb = lb * R(0.5);
+  for (int k = 0; k < 3; k++) { amid[k] = a0[k] + da[k] * ha; bmid[k] = b0[k] + db[k] * hb; trans[k] = amid[k] - bmid[k]; }
+  real dab = dot3(da, db), dat = dot3(da, trans), dbt = dot3(db, trans);
+  real denom = 1 - dab * dab;
+  real ta = (-dat + dab * dbt) / (denom + R(1e-6));
+  real tb = dbt + ta * dab;
+  ta = FMIN(FMAX(ta, -ha), ha);
+  tb = FMIN(FMAX(tb, -hb), hb);
+  for (int k = 0; k < 3; k++) { best_a[k] = amid[k] + da[k] * ta; best_b[k] = bmid[k] + db[k] * tb; }
+  real na[3], nb_[3];
+  closest_segment_point(na, a0, a1, best_b);
+  closest_segment_point(nb_, b0, b1, best_a);
+  real d1 = 0, d2 = 0;
+  for (int k = 0; k < 3; k++) { d1 += (na[k] - best_b[k]) * (na[k] - best_b[k]); d2 += (nb_[k] - best_a[k]) * (nb_[k] - best_a[k]); }
+  if (d1 < d2) { for (int k = 0; k < 3; k++) best_a[k] = na[k]; }
+  else { for (int k = 0; k < 3; k++) best_b[k] = nb_[k]; }
+}
+/* make_frame(n) [UP mjx math.make_frame]: rows n, b = normalise(y or z minus its part along n), n x b */
+static void make_frame(real* fr, const real* n) {
+  real b[3] = {0, 0, 0};
+  if (n[1] > R(-0.5) && n[1] < R(0.5)) b[1] = 1; else b[2] = 1;
+  real nb_ = dot3(n, b);
+  for (int k = 0; k < 3; k++) b[k] -= n[k] * nb_;
+  real bn = SQRT(dot3(b, b));
+  for (int k = 0; k < 3; k++) { b[k] /= bn; fr[k] = n[k]; fr[3 + k] = b[k]; }
+  cross(fr + 6, n, b);
+}
+/* two spheres (also the end of sphere-capsule / capsule-capsule)  [UP mjx collision_primitive._sphere_sphere]: normal from 1 to 2
+ * ((1, 0, 0) when the centres coincide), dist = |p2 - p1| - r1 - r2, pos = p1 + n (r1 + dist / 2) */
+static void sphere_sphere(real* dist_, real* pos, real* fr, const real* p1, real r1, const real* p2, real r2) {
+  real n[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+  real len = SQRT(dot3(n, n));
+  if (len == 0) { n[0] = 1; n[1] = n[2] = 0; } else { for (int k = 0; k < 3; k++) n[k] /= len; }
+  real dist = len - (r1 + r2);
+  for (int k = 0; k < 3; k++) pos[k] = p1[k] + n[k] * (r1 + dist * R(0.5));
+  make_frame(fr, n);
+  *dist_ = dist;
+}
+
 static void collision(const ref_model* m, ref_data* d) {
   for (int c = 0; c < m->ncon; c++) {
     int g1 = m->con_geom1[c], g2 = m->con_geom2[c], kind = m->con_kind[c];
+    if (kind >= CON_SPHERE_SPHERE) {     /* two moving geoms: sphere-sphere, sphere-capsule, capsule-capsule [UP mjx collision_primitive] */
+      const real *m1 = d->geom_xmat + 9 * g1, *p1 = d->geom_xpos + 3 * g1, *s1 = m->geom_size + 3 * g1;
+      const real *m2 = d->geom_xmat + 9 * g2, *p2 = d->geom_xpos + 3 * g2, *s2 = m->geom_size + 3 * g2;
+      real a[3] = {p1[0], p1[1], p1[2]}, b[3] = {p2[0], p2[1], p2[2]};
+      real e20[3], e21[3];
+      for (int k = 0; k < 3; k++) { e20[k] = p2[k] - m2[3 * k + 2] * s2[1]; e21[k] = p2[k] + m2[3 * k + 2] * s2[1]; }
+      if (kind == CON_SPHERE_CAPSULE) {
+        closest_segment_point(b, e20, e21, p1);
+      } else if (kind == CON_CAPSULE_CAPSULE) {
+        real e10[3], e11[3];
+        for (int k = 0; k < 3; k++) { e10[k] = p1[k] - m1[3 * k + 2] * s1[1]; e11[k] = p1[k] + m1[3 * k + 2] * s1[1]; }
+        closest_segment_to_segment(a, b, e10, e11, e20, e21);
+      }
+      sphere_sphere(d->con_dist + c, d->con_pos + 3 * c, d->con_frame + 9 * c, a, s1[0], b, s2[0]);
+      continue;
+    }
     const real* pm = d->geom_xmat + 9 * g1;
     const real* pp = d->geom_xpos + 3 * g1;
     const real* gm = d->geom_xmat + 9 * g2;
@@ -611,25 +683,33 @@ static void make_constraint(const ref_model* m, ref_data* d) {
     real mu = m->con_friction[5 * c];
     real k, b, imp;
     kbi(m, m->con_solref + 2 * c, m->con_solimp + 5 * c, dist, &k, &b, &imp);
-    real invw = (m->con_invweight[c] + mu * mu * m->con_invweight[c]) * 2 * mu * mu / m->impratio;
+    const int frictionless = m->con_dim[c] == 1;      /* condim 1: ONE row along the normal, invweight = the two bodies' [UP mjx constraint._instantiate_contact] */
+    real invw = frictionless ? m->con_invweight[c] : (m->con_invweight[c] + mu * mu * m->con_invweight[c]) * 2 * mu * mu / m->impratio;
     real r = FMAX(invw * (1 - imp) / imp, MINVAL);
     real* J0 = d->efc_J + (size_t)row * nv;
-    if (active) {
-      int dd = m->body_lastdof[body];
-      while (dd >= 0) {
-        const real* cd = d->cdof + 6 * dd;
-        real jp[3], t[3];
-        cross(t, cd, off);
-        for (int kk = 0; kk < 3; kk++) jp[kk] = cd[3 + kk] + t[kk];
-        real jn = dot3(fr, jp), j1 = dot3(fr + 3, jp), j2 = dot3(fr + 6, jp);
-        J0[dd] = jn + mu * j1;
-        J0[nv + dd] = jn - mu * j1;
-        J0[2 * nv + dd] = jn + mu * j2;
-        J0[3 * nv + dd] = jn - mu * j2;
-        dd = m->dof_parentid[dd];
+    if (active) {      /* J = jac(body2, pos) - jac(body1, pos) projected on the frame; a world body1 (floor contacts) has no dofs */
+      for (int side = 0; side < 2; side++) {
+        const real sg = side == 0 ? R(1.0) : R(-1.0);
+        int dd = m->body_lastdof[side == 0 ? body : m->con_body1[c]];
+        while (dd >= 0) {
+          const real* cd = d->cdof + 6 * dd;
+          real jp[3], t[3];
+          cross(t, cd, off);
+          for (int kk = 0; kk < 3; kk++) jp[kk] = cd[3 + kk] + t[kk];
+          real jn = dot3(fr, jp), j1 = dot3(fr + 3, jp), j2 = dot3(fr + 6, jp);
+          if (frictionless) {
+            J0[dd] += sg * jn;
+          } else {
+            J0[dd] += sg * (jn + mu * j1);
+            J0[nv + dd] += sg * (jn - mu * j1);
+            J0[2 * nv + dd] += sg * (jn + mu * j2);
+            J0[3 * nv + dd] += sg * (jn - mu * j2);
+          }
+          dd = m->dof_parentid[dd];
+        }
       }
     }
-    for (int kk = 0; kk < 4; kk++, row++) {
+    for (int kk = 0; kk < (frictionless ? 1 : 4); kk++, row++) {
       d->efc_D[row] = 1 / r;
       d->efc_pos[row] = dist;
       d->efc_aref[row] = -b * dotn(d->efc_J + (size_t)row * nv, d->qvel, nv) - k * imp * dist;

@@ -1,12 +1,14 @@
 """BASELINE config 1: `Rodent_Env_Brax.step()` with num_envs = 4 on rodent_cpu.xml, CPU (plumbing, no GPU).
 
 rodent_cpu.xml [REF models/rodent_cpu.xml] has no free joint and no floor, 8 fixed tendons driving 8 of its 38 actuators, and
-~4.3 k self-collision pairs of primitives this build does not implement.  What is exercised: the MJCF
-compiler on that file (dims, tendon transmission tables), the env reset / step arithmetic on the CPU oracle for 4 envs with
-contacts off (shapes, finite outputs, determinism, joint limits active), the tendon transmission in BOTH CPU formulations
-(C oracle: sparse entries; np_ref: dense moment matrix), and that the HIP library refuses this model instead of mis-running it.
-Deviation, stated: contacts are OFF for this model (ndropped_pairs recorded in the blob); the env's `qpos[:3] = track_pos`
-and `q[2]` health test act on hinge angles here, exactly as the reference code would."""
+4271 self-collision pairs.  Round 3: the 2243 sphere / capsule pairs are compiled and collide on the CPU oracles (sphere-sphere,
+sphere-capsule, capsule-capsule, condim 1 and 3; tests/test_self_collision_cpu.py); the 2028 pairs that involve an ellipsoid or a box
+stay dropped (count kept in the blob).  What is exercised here: the MJCF compiler on that file (dims, tendon
+transmission tables), the env reset / step arithmetic on the CPU oracle for 4 envs (shapes, finite outputs, determinism, joint limits
+active), the tendon transmission in BOTH CPU formulations (C oracle: sparse entries; np_ref: dense moment matrix), and that the HIP
+library refuses this model instead of mis-running it (contacts between two moving bodies and tendon transmissions have no kernel
+instance: the J-free products of the step kernel walk ONE ancestor chain per contact).  The env's `qpos[:3] = track_pos` and `q[2]`
+health test act on hinge angles here, exactly as the reference code would."""
 import os
 
 import numpy as np
@@ -21,8 +23,8 @@ from tests.oracle_env import OracleRodent
 def test_compiled_dims_and_tendon_tables():
     m = mjcf.load_blob(assets.asset_path("rodent_cpu"))
     got = {k: int(m[k]) for k in ("nbody", "nq", "nv", "nu", "ngeom", "nM", "ntendon", "ncon", "nlimit", "hip_supported")}
-    assert got == dict(nbody=66, nq=67, nv=67, nu=38, ngeom=100, nM=696, ntendon=8, ncon=0, nlimit=67, hip_supported=0)
-    assert 4000 < int(m["ndropped_pairs"]) < 4600
+    assert got == dict(nbody=66, nq=67, nv=67, nu=38, ngeom=100, nM=696, ntendon=8, ncon=2243, nlimit=67, hip_supported=0)
+    assert int(m["ncon"]) + int(m["ndropped_pairs"]) == 4271
     adr = m["actuator_momentadr"]
     assert (np.diff(adr)[:8] == [2, 2, 2, 3, 2, 2, 12, 12]).all() and (np.diff(adr)[8:] == 1).all()      # [REF models/rodent_cpu.xml:505-560]
     for u in range(6):          # lumbar / cervical tendons: coefficients sum to 1
