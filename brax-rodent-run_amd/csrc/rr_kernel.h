@@ -172,7 +172,8 @@ struct RRIO {
   // runs at close to single-wave speed while the partner, which is ahead, has slack.  Timing only -- results are unaffected.
   unsigned* progress;
   float pace_t1, pace_t2, pace_t3;   // env steps behind the average for priority levels 1, 2, 3
-  int pace_mode;                     // 0: max(weight level, lag level); 1: lag level only; 2: sum, capped at 3
+  int pace_mode;                     // bits 0-1: 0 max(weight level, lag level), 1 lag level only, 2 sum capped at 3; bit 2 (4): progress counted
+                                     // per SUBSTEP (ten times finer); bit 3 (8): the factor-phase priority is 3 for laggards, 2 otherwise
   int mode;  // 0 = forward only (pipeline_init), 1 = step; bit 1 (2) = env epilogue as reset (obs only)
   int pad_;
 };
@@ -482,8 +483,8 @@ struct Wave {
     // ... raised for an environment that has fallen behind the others of a multi-step launch (lag_prio, set by the kernel per env step)
     const int by_weight = jnact >= 12 ? 3 : (jnact >= 6 ? 2 : (jnact >= 2 ? 1 : 0));
     int p = by_weight > lag_prio ? by_weight : lag_prio;
-    if (lag_mode == 1) p = lag_prio;                                         // progress only
-    else if (lag_mode == 2) p = by_weight + lag_prio > 3 ? 3 : by_weight + lag_prio;
+    if ((lag_mode & 3) == 1) p = lag_prio;                                         // progress only
+    else if ((lag_mode & 3) == 2) p = by_weight + lag_prio > 3 ? 3 : by_weight + lag_prio;
     if (p >= 3) __builtin_amdgcn_s_setprio(3);          // (s_setprio takes an immediate)
     else if (p == 2) __builtin_amdgcn_s_setprio(2);
     else if (p == 1) __builtin_amdgcn_s_setprio(1);
@@ -2173,7 +2174,8 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * RR_LANES, (NVS >= 3 ? 1 : 2)) void
     // its instructions go out the moment they are ready (-1.2 ... -1.6 % launch time; the same for the solves, the line-search
     // iterations or the tree sweeps measured +0.3 ... +0.6 % each and +3 % together)
 #if RR_FACTOR_PRIO
-    __builtin_amdgcn_s_setprio(3);
+    if ((w.lag_mode & 8) && w.lag_prio == 0) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
 #endif
     w.factor();
     if (dg) for (int e = lane; e < D.nM; e += RR_LANES) dg[D.g_qLD + e] = w.s_qLD[2 * e];
@@ -2209,6 +2211,17 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * RR_LANES, (NVS >= 3 ? 1 : 2)) void
     }
     if (mode & 1) w.euler();
     w.template stamp<PROF>(13);
+    if (UNROLL && !last) {       // pacing at substep granularity (RRIO::pace_mode bit 2)
+      const RRIO iop = load_io();
+      if (iop.progress && (iop.pace_mode & 4)) {
+        unsigned seen = 0;
+        if (lane == 0) seen = __hip_atomic_fetch_add(iop.progress, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        seen = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);
+        const float behind = ((float)seen / (float)num_envs - (float)(ut * frames + f + 1)) / (float)frames;      // in env steps
+        w.lag_prio = behind > iop.pace_t3 ? 3 : (behind > iop.pace_t2 ? 2 : (behind > iop.pace_t1 ? 1 : 0));
+        w.lag_mode = iop.pace_mode;
+      }
+    }
   }
 
   w.template stamp<PROF>(14);
@@ -2317,7 +2330,8 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * RR_LANES, (NVS >= 3 ? 1 : 2)) void
         unsigned seen = 0;
         if (lane == 0) seen = __hip_atomic_fetch_add(io.progress, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
         seen = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);
-        const float behind = (float)seen / (float)num_envs - (float)(ut + 1);      // env steps behind the average environment
+        const float per_step = (io.pace_mode & 4) ? (float)frames : 1.0f;          // the counter's units per env step
+        const float behind = ((float)seen / (float)num_envs) / per_step - (float)(ut + 1);      // env steps behind the average environment
         w.lag_prio = behind > io.pace_t3 ? 3 : (behind > io.pace_t2 ? 2 : (behind > io.pace_t1 ? 1 : 0));
         w.lag_mode = io.pace_mode;
       }

@@ -131,12 +131,15 @@ def test_evaluator_metrics_against_the_oracle(oracle_built):
     # restatement over the ORACLE's per-step outputs (teacher-forced from the recorded states): EvalWrapper sums metric * active,
     # active *= 1 - done, where done is the Episode wrapper's (env done, or steps >= EP)
     A = parity.OracleEnvImpl("rodent_optimized", N, "f64", (8, 8), track, z_range=(0.05, 0.5))
+    B = parity.OracleEnvImpl("rodent_optimized", N, "f32", (8, 8), track, z_range=(0.05, 0.5))      # the yardstick of criterion C3
     active = np.ones(N)
     sums = dict(reward=np.zeros(N), pos_reward=np.zeros(N), reward_quadctrl=np.zeros(N), reward_alive=np.zeros(N))
+    sums32 = {k: np.zeros(N) for k in sums}
     steps = np.zeros(N)
     ended_early = 0
     for state, action, ns in rec.log:
         w = A.env_step(_state_of(state), _np(action), state.info["cur_frame"].cpu().numpy())
+        w32 = B.env_step(_state_of(state), _np(action), state.info["cur_frame"].cpu().numpy())
         ep_steps = np.where(_np(state.done) != 0, 0.0, _np(state.info["steps"])) + 1
         done = np.where(ep_steps >= EP, 1.0, w["done"])
         np.testing.assert_array_equal(_np(ns.info["steps"]), ep_steps)
@@ -146,11 +149,16 @@ def test_evaluator_metrics_against_the_oracle(oracle_built):
         done = _np(ns.done)                          # at the threshold follow the HIP decision (float32 vs float64 side of it)
         steps += active
         sums["reward"] += w["reward"] * active
+        sums32["reward"] += w32["reward"] * active
         for i, k in enumerate(("pos_reward", "reward_quadctrl", "reward_alive")):
             sums[k] += w["metrics"][:, i] * active
+            sums32[k] += w32["metrics"][:, i] * active
         ended_early += int(((done != 0) & (ep_steps < EP) & (active != 0)).sum())
         active = active * (1 - done)
     assert ended_early >= 1 and ended_early < N                     # both kinds of episode are in the sample
     assert abs(got["eval/avg_episode_length"] - steps.mean()) < 1e-6
+    # pos_reward = exp(-100 |dx|) magnifies a position error a hundredfold, so the bound is C3's: within 3x what the scalar float32 oracle
+    # loses on the same (teacher-forced) steps, plus a floor for the single sample a mean is
     for k, v in sums.items():
-        assert abs(got["eval/episode_" + k] - v.mean()) <= 2e-4 * max(1.0, abs(v.mean())), (k, got["eval/episode_" + k], v.mean())
+        gap = abs(sums32[k].mean() - v.mean())
+        assert abs(got["eval/episode_" + k] - v.mean()) <= 3 * gap + 3e-4 * max(1.0, abs(v.mean())), (k, got["eval/episode_" + k], v.mean(), gap)
