@@ -42,6 +42,7 @@ struct rr_model {
   // blob's h_* tables; pair_ok = the blob carries them and a PAIR kernel instance matches
   bool pair_ok = false;
   RRDims kd_rep;
+  bool dyn = false;        // candidate-pair contacts between moving bodies / condim 1 / tendon transmissions (rr_kernel.h DYN; blob k_dyn)
   mutable std::atomic<int> live_batches{0};     // batches bake the model's LDS layout at creation: the solver type is fixed while any exist
 
   const Entry* find(const char* n) const { auto it = e.find(n); return it == e.end() ? nullptr : &it->second; }
@@ -52,7 +53,8 @@ struct rr_model {
 static void layout(rr_model* m) {
   RRDims& k = m->kd;
   const rr_dims& d = m->dims;
-  const RRLayout L = rr_layout(d.nq, d.nv, d.nu, d.nbody, d.nM, d.ncon, m->solver == 2);
+  const int con_slots = m->dyn ? m->NCS * RR_LANES : d.ncon;      // DYN: the wave holds the pairs in penetration in its contact slots
+  const RRLayout L = rr_layout(d.nq, d.nv, d.nu, d.nbody, d.nM, con_slots, m->solver == 2);
   k.o_H = L.o_H; k.o_Mp = L.o_Mp; k.o_anc = L.o_anc; k.solver = m->solver;
   m->dbg_names.clear(); m->dbg_off.clear(); m->dbg_size.clear(); m->dbg_cnames.clear();      // layout() may run again (rr_model_set_solver_type)
   k.o_qpos = L.o_qpos; k.o_qvel = L.o_qvel; k.o_act = L.o_act; k.o_ctrl = L.o_ctrl; k.o_xpos = L.o_xpos; k.o_xquat = L.o_xquat;
@@ -60,7 +62,8 @@ static void layout(rr_model* m) {
   k.o_arm = L.o_arm; k.o_warm = L.o_warm; k.o_qact = L.o_qact; k.o_jlist = L.o_jlist; k.lds_floats = L.lds_floats;
   const int o = L.lds_floats;
   // staging of the line search's compacted rows: cinert | cvel | pose regions each hold 4*ncon + nv floats
-  m->stage_ok = 2 * (d.nbody + 8) <= std::max(7 * d.nbody + 4, 6 * d.nv) && 6 * d.ncon <= std::max(7 * d.nbody + 4, 6 * d.nv) && 4 * d.ncon + d.nv <= std::min(std::min(10 * d.nbody, 6 * d.nbody), std::max(7 * d.nbody + 4, 6 * d.nv));
+  m->stage_ok = 2 * (d.nbody + 8) <= std::max(7 * d.nbody + 4, 6 * d.nv) && 6 * con_slots <= std::max(7 * d.nbody + 4, 6 * d.nv) && 4 * con_slots + d.nv <= std::min(std::min(10 * d.nbody, 6 * d.nbody), std::max(7 * d.nbody + 4, 6 * d.nv));
+  if (m->dyn && d.nu > std::max(7 * d.nbody + 4, 6 * d.nv)) m->stage_ok = false;      // actuator forces go through the pose cells
   // debug dump
   int g = 0;
   auto dbg = [&](const char* name, int n) { int r = g; m->dbg_names.push_back(name); m->dbg_off.push_back(g); m->dbg_size.push_back(n); g += n; return r; };
@@ -153,6 +156,7 @@ extern "C" int rr_model_load(const char* path, rr_model** out) {
                                "k_body_i", "k_body_f", "k_jnt_i", "k_jnt_f", "k_dof_i", "k_dof_f", "k_act_f", "k_M_ij_k", "k_body_anc",
                                "k_nround", "k_factor3", "k_factor3_rows", "k_linv", "k_linv_rows", "k_coljob", "k_rowjob",
                                "k_jobown", "k_solve_lmax", "k_solve_cmax", "k_solve_rmax", "k_con_i", "k_con_f", "k_con_chain_packed", "k_con_chain_rows", "k_root_mass",
+                               "k_act_i", "k_act_m_i", "k_act_m_f",
                                "dof_depth", "body_depth", "opt_timestep", "opt_gravity", "stat_meaninertia"};
   for (const char* nme : need)
     if (!m->find(nme)) { std::string s = std::string("rr_model_load: blob lacks '") + nme + "'"; delete m; return fail(RR_EIO, s); }
@@ -165,6 +169,9 @@ extern "C" int rr_model_load(const char* path, rr_model** out) {
   d.timestep = m->fscalar("opt_timestep");
   const int32_t* sl = (const int32_t*)m->find("k_slots")->data;
   m->NBS = sl[0]; m->NVS = sl[1]; m->NCS = sl[2];
+  m->dyn = m->iscalar("k_dyn") != 0;
+  if (m->dyn && (m->find("k_con_i")->dims[1] != 8 || m->find("k_con_f")->dims[1] != 32 || (int)m->find("k_con_chain_rows")->count != 10 * (d.ncon + 1) || d.nv >= 128 || d.nu > RR_LANES)) {
+    delete m; return fail(RR_EIO, "rr_model_load: candidate-pair tables do not match the DYN kernel instance (stale blob)"); }
   RRDims& k = m->kd;
   memset(&k, 0, sizeof(k));
   k.nq = d.nq; k.nv = d.nv; k.nu = d.nu; k.nbody = d.nbody; k.njnt = d.njnt; k.nM = d.nM; k.ncon = d.ncon;
@@ -187,7 +194,7 @@ extern "C" int rr_model_load(const char* path, rr_model** out) {
   if (k.nroot > 2) { delete m; return fail(RR_EUNSUPPORTED, "rr_model_load: more than 2 kinematic trees"); }
   if (m->find("k_dof_i")->dims[1] != RR_DOFI) { delete m; return fail(RR_EIO, "rr_model_load: k_dof_i width mismatch (stale blob)"); }
   if (m->find("k_body_i")->dims[1] != RR_BODYI) { delete m; return fail(RR_EIO, "rr_model_load: k_body_i width mismatch (stale blob)"); }
-  if (d.nv > 256 || d.ncon > 256) { delete m; return fail(RR_EUNSUPPORTED, "rr_model_load: nv/ncon above the 8-bit table index"); }
+  if (d.nv > 256 || (!m->dyn && d.ncon > 256)) { delete m; return fail(RR_EUNSUPPORTED, "rr_model_load: nv/ncon above the 8-bit table index"); }
   if (m->find("k_con_chain_packed")->dims[1] != m->NCS * RR_LANES) { delete m; return fail(RR_EIO, "rr_model_load: lane-table width mismatch"); }
   k.nv_scale = d.nv > 1 ? d.nv : 1;
   layout(m);
@@ -211,7 +218,7 @@ extern "C" int rr_model_set_solver_type(rr_model* m, int32_t solver) {
   if (!m || (solver != 1 && solver != 2)) return fail(RR_EINVAL, "rr_model_set_solver_type: solver must be 1 (cg) or 2 (newton)");
   if (solver != m->solver && m->live_batches.load() > 0)
     return fail(RR_EINVAL, "rr_model_set_solver_type: batches of this model exist (they hold the LDS layout of the current solver); set the solver before rr_batch_create");
-  if (solver == 2 && !(m->NBS == 2 && m->NVS == 2 && m->NCS == 1))
+  if (solver == 2 && (!(m->NBS == 2 && m->NVS == 2 && m->NCS == 1) || m->dyn))
     return fail(RR_EUNSUPPORTED, "rr_model_set_solver_type: the Newton instance exists for the single-rodent models only");
   if (solver == 2 && 4 * ((m->dims.nv + 3) & ~3) > std::max(7 * m->dims.nbody + 4, 6 * m->dims.nv))
     return fail(RR_EUNSUPPORTED, "rr_model_set_solver_type: the four Hessian rows do not fit the pose cells");
@@ -299,6 +306,8 @@ static int upload_levels(rr_batch* b, const char* name, rr_gi* dst, uint32_t bas
 // launch when rr_outputs.debug is given), cycle-stamp profile (diagnostic, rodent dims or generic 2,2,1).
 static kern_t pick_kernel(const rr_model* m, bool prof = false, bool dbg = false) {
   const int nbs = m->NBS, nvs = m->NVS, ncs = m->NCS;
+  if (m->dyn)        // candidate-pair contacts: one production instance (generic dimensions); no debug dump, no profile build
+    return (!prof && !dbg && m->solver != 2 && nbs == 2 && nvs == 2 && ncs == 1) ? rr_step_kernel<2, 2, 1, false, false, RRDims, false, false, false, false, true> : nullptr;
   if (prof && m->solver != 2) return (nbs == 2 && nvs == 2 && ncs == 1) ? (RRDimsRodent::matches(m->kd) ? rr_step_kernel<2, 2, 1, true, false, RRDimsRodent> : rr_step_kernel<2, 2, 1, true, false, RRDims>) : nullptr;
   if (m->solver == 2)     // Newton: the (2,2,1) generic instances only (rr_model_set_solver_type checks)
     return prof ? nullptr : (dbg ? rr_step_kernel<2, 2, 1, false, true, RRDims, true> : rr_step_kernel<2, 2, 1, false, false, RRDims, true>);
@@ -317,7 +326,7 @@ static kern_t pick_kernel(const rr_model* m, bool prof = false, bool dbg = false
 }
 
 static kern_t pick_unroll_kernel(const rr_model* m, bool actor = false) {
-  if (m->solver == 2 || !(m->NBS == 2 && m->NVS == 2 && m->NCS == 1)) return nullptr;
+  if (m->solver == 2 || m->dyn || !(m->NBS == 2 && m->NVS == 2 && m->NCS == 1)) return nullptr;
   if (actor) return RRDimsRodent::matches(m->kd) ? rr_step_kernel<2, 2, 1, false, false, RRDimsRodent, false, true, true>
                     : (RRDimsRodentNew::matches(m->kd) ? rr_step_kernel<2, 2, 1, false, false, RRDimsRodentNew, false, true, true> : rr_step_kernel<2, 2, 1, false, false, RRDims, false, true, true>);
   return RRDimsRodent::matches(m->kd) ? rr_step_kernel<2, 2, 1, false, false, RRDimsRodent, false, true>
@@ -341,6 +350,7 @@ extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t devi
   UP(body_anc, "k_body_anc") UP(con_chain_rows, "k_con_chain_rows") UP(coljob, "k_coljob") UP(rowjob, "k_rowjob") UP(jobown, "k_jobown") UP(con_i, "k_con_i")
   UP(body_f, "k_body_f") UP(jnt_f, "k_jnt_f") UP(dof_f, "k_dof_f")
   UP(act_f, "k_act_f") UP(con_f, "k_con_f") UP(root_mass, "k_root_mass")
+  UP(act_i, "k_act_i") UP(act_m_i, "k_act_m_i") UP(act_m_f, "k_act_m_f")
 #undef UP
   if ((rc = upload_levels(b, "k_factor3", &b->T.factor3)) || (rc = upload_levels(b, "k_linv", &b->T.linv))) { rr_batch_destroy(b); return rc; }
   memset(&b->T_rep, 0, sizeof(b->T_rep));

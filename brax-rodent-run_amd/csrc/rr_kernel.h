@@ -127,6 +127,8 @@ typedef const float __attribute__((address_space(1)))* rr_gf;
 struct RRTables {
   rr_gi factor3, linv, coljob, rowjob, jobown, body_i, jnt_i, dof_i, M_ij_k, body_anc, con_chain_rows, con_i, anc4;
   rr_gf body_f, jnt_f, dof_f, act_f, con_f, root_mass;
+  rr_gi act_i, act_m_i;      // transmission (DYN instances): per actuator (first moment entry, count); per entry (dof, qpos address)
+  rr_gf act_m_f;             // ... coefficient per entry
 };
 
 struct RRIO {
@@ -398,7 +400,12 @@ typedef float rr_f2 __attribute__((ext_vector_type(2)));
 // workgroup is TWO wavefronts, wave r steps replica r on the tables of one replica in its own LDS region, and the only coupling is the
 // CG solver's scalars (cost, gradient norm, line-search sums, Polak-Ribiere beta): every such wave sum is followed by an exchange
 // through LDS (solver_sum_n), after which both waves hold the same totals and take the same branches.
-template <int NBS, int NVS, int NCS, class DT, bool NEWTON = false, bool PAIR = false>
+// DYN (rodent_cpu.xml): the model's contact list is a list of CANDIDATE pairs of two moving geoms (sphere / capsule); every
+// substep the wave scans it, keeps the pairs in penetration in its 64 * NCS contact slots (in list order, by ballot), and works on those:
+// J = jac(body2) - jac(body1) through SIGNED dof chains (the dofs on exactly one of the two ancestor chains; J x) and a two-interval
+// membership test (J' f); contacts of condim 1 carry one row (rows 1..3 of the slot get D = 0); transmissions with several joints (fixed
+// tendons) go through per-actuator sums.  Production physics + env epilogue only.
+template <int NBS, int NVS, int NCS, class DT, bool NEWTON = false, bool PAIR = false, bool DYN = false>
 struct Wave {
   const DT& D;
   const RRTables& T;
@@ -428,9 +435,14 @@ struct Wave {
   int blast[NBS];         // last body of the subtree (bodies are in DFS order)
   int dofc0[NVS], dofc1[NVS];   // packed per-dof constants: depth | kind<<8 | root<<12 | body<<16 | parent-of-body<<24 ; Madr | last_desc<<16
   // J*x jobs (contact_jobs): the ancestor chains of the contacts in penetration are cut into pieces, one per lane
-  int jch[NCS][9];        // dof ids of this lane's piece, 4 per register
+  static constexpr int JW = DYN ? 10 : 9;       // ints of a chain row (4 ids each)
+  int jch[NCS][JW];       // dof ids of this lane's piece, 4 per register (DYN: bit 7 = the dof enters with a minus sign)
   int con_rank[NCS];      // rank of this lane's contact among the contacts in penetration
   int con_leaf[NCS];      // last dof of the contact's chain
+  int con_leaf1[NCS];     // DYN: last dof of body1's chain (-1: world)
+  int con_pid[NCS];       // DYN: candidate pair held by this slot
+  int con_nrow[NCS];      // DYN: rows of the slot's contact (4 = pyramid, 1 = frictionless)
+  int dyn_overflow = 0;   // DYN: pairs in penetration beyond the slots (dropped; reported through RRIO::cost bit 31)
   int jP, jLp, jnact;     // wave-uniform: lanes per contact (4 / 2 / 1), ids per piece (12 / 20 / 36), contacts in penetration
   // per-dof registers (slot s -> dof lane + 64 s)
   float dinv[NVS], dinvB[NVS];   // 1/D of M's factor, and of the eulerdamp matrix M + dt*diag(damping)
@@ -1159,6 +1171,21 @@ struct Wave {
 
   // ---------------------------------------------------------------- passive + actuation + qfrc_smooth (per dof)
   __device__ __forceinline__ void smooth_forces(float* bias_out, float* passive_out) {
+    if (DYN) {      // transmission with several joints per actuator (fixed tendons [REF models/rodent_cpu.xml:505-560]; UP mjx smooth.transmission):
+                    // lane = actuator: length = sum coef qpos, velocity = sum coef qvel, force -> the (dead) pose cells, read per dof below
+      if (lane < D.nu) {
+        const int u = lane, e0 = T.act_i[2 * u], ne = T.act_i[2 * u + 1];
+        float len = 0.0f, vel = 0.0f;
+        for (int e = 0; e < ne; ++e) {
+          const float c = T.act_m_f[e0 + e];
+          len += c * s_qpos[T.act_m_i[2 * (e0 + e) + 1]];
+          vel += c * s_qvel[T.act_m_i[2 * (e0 + e)]];
+        }
+        auto af = T.act_f + 8 * u;
+        s_buf[u] = af[0] * s_act[u] + af[1] + af[2] * len + af[3] * vel;
+      }
+      sync();
+    }
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
       const int d = lane + RR_LANES * s;
@@ -1174,15 +1201,20 @@ struct Wave {
         float actf = 0.0f;
         const int u = di[7];
         if (u >= 0) {
-          auto af = T.act_f + 8 * u;
-          const float a = s_act[u];
-          actf = af[0] * a + af[1] + af[2] * s_qpos[di[6]] + af[3] * qv;
+          if (DYN) {
+            actf = df[14] * s_buf[u];          // moment coefficient of this dof x the actuator's force
+          } else {
+            auto af = T.act_f + 8 * u;
+            const float a = s_act[u];
+            actf = af[0] * a + af[1] + af[2] * s_qpos[di[6]] + af[3] * qv;
+          }
         }
         s_qact[d] = actf;
         qfrc_smooth[s] = passive - bias + actf;
         bias_out[s] = bias; passive_out[s] = passive;
       }
     }
+    if (DYN) sync();      // every lane has read the actuator forces before the pose cells are reused
   }
 
   // ---------------------------------------------------------------- A-4 collision: contact geometry -> registers
@@ -1268,6 +1300,116 @@ struct Wave {
     }
   }
 
+  // ---------------------------------------------------------------- DYN: candidate pairs of two moving geoms [UP mjx collision_primitive]
+  // closest point of segment [a, b] to pt: t = (pt - a).ab / (ab.ab + 1e-6), clipped  [UP mjx math.closest_segment_point]
+  static __device__ __forceinline__ v3 seg_point(v3 a, v3 b, v3 pt) {
+    const v3 ab = b - a;
+    float t = dot(pt - a, ab) / (dot(ab, ab) + 1e-6f);
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    return a + ab * t;
+  }
+  // closest points of two segments [UP mjx math.closest_segment_to_segment_points]: line-line solution from the mid-points (denominator
+  // + 1e-6), clipped; then each clipped point re-projected on the other segment and the closer pair kept
+  static __device__ __forceinline__ void seg_seg(v3 a0, v3 a1, v3 b0, v3 b1, v3& pa, v3& pb) {
+    v3 da = a1 - a0, db = b1 - b0;
+    const float la = sqrtf(dot(da, da)), lb = sqrtf(dot(db, db));
+    da = da * (la > 0.0f ? 1.0f / la : 0.0f); db = db * (lb > 0.0f ? 1.0f / lb : 0.0f);
+    const float ha = 0.5f * la, hb = 0.5f * lb;
+    const v3 am = a0 + da * ha, bm = b0 + db * hb, tr = am - bm;
+    const float dab = dot(da, db), dat = dot(da, tr), dbt = dot(db, tr);
+    float ta = (-dat + dab * dbt) / (1.0f - dab * dab + 1e-6f);
+    float tb = dbt + ta * dab;
+    ta = fminf(fmaxf(ta, -ha), ha);
+    tb = fminf(fmaxf(tb, -hb), hb);
+    pa = am + da * ta; pb = bm + db * tb;
+    const v3 na = seg_point(a0, a1, pb), nb = seg_point(b0, b1, pa);
+    const v3 e1 = na - pb, e2 = nb - pa;
+    if (dot(e1, e1) < dot(e2, e2)) pa = na; else pb = nb;
+  }
+  // pair p: signed distance, contact point, normal (geom1 -> geom2); kinds 4 sphere-sphere, 5 sphere-capsule, 6 capsule-capsule
+  __device__ __forceinline__ float pair_geometry(int p, v3& pos, v3& n) const {
+    auto ci = T.con_i + 8 * p;
+    auto cf = T.con_f + 32 * p;
+    const int kind = ci[0], b1 = ci[1], b2 = ci[2];
+    v3 c[2], ax[2];
+    float rad[2], hl[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int b = g ? b2 : b1;
+      float bq[4], gq[4], q[4], xm[9], gm[9];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { bq[k] = s_xquat[4 * b + k]; gq[k] = cf[10 * g + 3 + k]; }
+      quat_to_mat(xm, bq);
+      c[g] = ld3(s_xpos + 3 * b) + mat_vec(xm, ld3(cf + 10 * g));
+      quat_mul(q, bq, gq);
+      quat_to_mat(gm, q);
+      ax[g] = mk3(gm[2], gm[5], gm[8]);
+      rad[g] = cf[10 * g + 7]; hl[g] = cf[10 * g + 8];
+    }
+    v3 pa = c[0], pb = c[1];
+    if (kind == 5) pb = seg_point(c[1] - ax[1] * hl[1], c[1] + ax[1] * hl[1], c[0]);
+    else if (kind == 6) seg_seg(c[0] - ax[0] * hl[0], c[0] + ax[0] * hl[0], c[1] - ax[1] * hl[1], c[1] + ax[1] * hl[1], pa, pb);
+    const v3 d = pb - pa;
+    const float len = sqrtf(dot(d, d));
+    n = len == 0.0f ? mk3(1, 0, 0) : d * (1.0f / len);
+    const float dist = len - (rad[0] + rad[1]);
+    pos = pa + n * (rad[0] + 0.5f * dist);
+    return dist;
+  }
+  __device__ __forceinline__ void contact_geometry_dyn() {
+    int count = 0;
+    for (int p0 = 0; p0 < D.ncon; p0 += RR_LANES) {          // scan: which candidate pairs are in penetration
+      const int p = p0 + lane;
+      bool pen = false;
+      if (p < D.ncon) { v3 pos_, n_; pen = pair_geometry(p, pos_, n_) < 0.0f; }
+      const unsigned long long mk = __ballot(pen);
+      if (pen) {
+        const int slot = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+        if (slot < WC) s_jlist[slot] = p;
+      }
+      count += __popcll(mk);
+    }
+    dyn_overflow = count > WC ? 1 : 0;
+    if (count > WC) count = WC;
+    sync();
+#pragma unroll
+    for (int cs = 0; cs < NCS; ++cs) {
+      const int slot = lane + RR_LANES * cs;
+      con_act[cs] = false; con_mu[cs] = 0; con_D[cs] = 0; con_nanc[cs] = 0; con_kk[cs] = 0; con_b[cs] = 0;
+      con_pid[cs] = 0; con_leaf[cs] = 0; con_leaf1[cs] = -1; con_nrow[cs] = 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { con_aref[cs][k] = 0; con_jar[cs][k] = 0; con_jv[cs][k] = 0; }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) con_off[cs][k] = 0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) con_fr[cs][k] = 0;
+      if (slot < count) {
+        const int p = s_jlist[slot];
+        auto ci = T.con_i + 8 * p;
+        auto cf = T.con_f + 32 * p;
+        v3 pos, n;
+        const float dist = pair_geometry(p, pos, n);
+        const v3 yb = (n.y > -0.5f && n.y < 0.5f) ? mk3(0, 1, 0) : mk3(0, 0, 1);       // make_frame(n)
+        v3 fb = yb - n * dot(n, yb);
+        fb = fb * (1.0f / sqrtf(dot(fb, fb)));
+        const v3 fc = cross(n, fb);
+        con_act[cs] = true;           // the scan selected it: dist < 0 (same arithmetic)
+        con_pid[cs] = p; con_leaf1[cs] = ci[5]; con_leaf[cs] = ci[6]; con_nrow[cs] = ci[7]; con_nanc[cs] = ci[4];
+        float k, bcoef, imp;
+        { const float si_[5] = {cf[24], cf[25], cf[26], cf[27], cf[28]}; kbi(D.dt, cf[22], cf[23], si_, dist, k, bcoef, imp); }
+        const float rr = fmaxf(cf[21] * (1.0f - imp) / imp, RR_MINVAL);
+        con_mu[cs] = con_nrow[cs] == 1 ? 0.0f : cf[20]; con_D[cs] = 1.0f / rr;
+        con_kk[cs] = k * imp * dist; con_b[cs] = bcoef;
+        const v3 off = pos - get_com(ci[3]);
+        con_off[cs][0] = off.x; con_off[cs][1] = off.y; con_off[cs][2] = off.z;
+        con_fr[cs][0] = n.x; con_fr[cs][1] = n.y; con_fr[cs][2] = n.z;
+        con_fr[cs][3] = fb.x; con_fr[cs][4] = fb.y; con_fr[cs][5] = fb.z;
+        con_fr[cs][6] = fc.x; con_fr[cs][7] = fc.y; con_fr[cs][8] = fc.z;
+      }
+    }
+    sync();
+  }
+
   // ---------------------------------------------------------------- A-5 constraint rows (limits; contact aref)
   __device__ __forceinline__ void constraint_rows(float* dbg) {
 #pragma unroll
@@ -1324,11 +1466,12 @@ struct Wave {
     }
     jnact = n_act;
     jP = 4 * n_act <= RR_LANES * NCS ? 4 : (2 * n_act <= RR_LANES * NCS ? 2 : 1);
-    jLp = jP == 4 ? 12 : (jP == 2 ? 20 : 36);
+    jLp = jP == 4 ? 12 : (jP == 2 ? 20 : (DYN ? 40 : 36));
     const int sh = jP == 4 ? 2 : (jP == 2 ? 1 : 0);
 #pragma unroll
     for (int cs = 0; cs < NCS; ++cs) {
       const int c = lane + RR_LANES * cs;
+      if (DYN) continue;           // DYN: the slots ARE the contacts in penetration (rank = slot) and s_jlist already holds their pair ids
       if (con_act[cs]) s_jlist[con_rank[cs]] = c;
       con_leaf[cs] = c < D.ncon ? (g_int(T.con_chain_rows, 9 * c) & 255) : 0;
     }
@@ -1338,15 +1481,15 @@ struct Wave {
       const int J = lane + RR_LANES * js, r = J >> sh, p = J & (jP - 1);
       const int pad = D.nv * 0x01010101;      // dof id nv: zero motion vector, zero vector cell
 #pragma unroll
-      for (int k = 0; k < 9; ++k) jch[js][k] = pad;
+      for (int k = 0; k < JW; ++k) jch[js][k] = pad;
       if (r < n_act) {
         const int c = s_jlist[r], start = p * jLp;
         const int left = g_int(T.con_i, 8 * c + 4) - start;
         const int n = left < 0 ? 0 : (left > jLp ? jLp : left);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
+        for (int k = 0; k < JW; ++k) {
           if (4 * k < jLp) {
-            const int v = g_int(T.con_chain_rows, 9 * c + (start >> 2) + k);   // the table has a slack row
+            const int v = g_int(T.con_chain_rows, JW * c + (start >> 2) + k);   // the table has a slack row
             const int keep = n - 4 * k;                                          // ids of this int that belong to the piece
             const unsigned msk = keep >= 4 ? 0xFFFFFFFFu : (keep <= 0 ? 0u : (1u << (8 * keep)) - 1u);
             jch[js][k] = (v & msk) | (pad & ~msk);
@@ -1365,12 +1508,14 @@ struct Wave {
     for (int js = 0; js < NCS; ++js) {
       float w[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-      for (int t0 = 0; t0 < 36; t0 += 4) {
+      for (int t0 = 0; t0 < 4 * JW; t0 += 4) {
         if (t0 < jLp) {     // wave-uniform; no per-lane predicate: ids beyond the piece are nv (zero vector)
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const int dd = (opaque(jch[js][t0 >> 2]) >> (8 * u)) & 255;
-            const float xv = vec[dd];
+            const int id = (opaque(jch[js][t0 >> 2]) >> (8 * u)) & 255;
+            const int dd = DYN ? (id & 127) : id;
+            float xv = vec[dd];
+            if (DYN && (id & 128)) xv = -xv;           // a dof of body1's chain: J = jac(body2) - jac(body1)
             const float* cd = s_cdof + 6 * dd;
 #pragma unroll
             for (int i = 0; i < 6; ++i) w[i] += cd[i] * xv;
@@ -1432,7 +1577,7 @@ struct Wave {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float jr = con_jar[cs][k];
-          if (jr < 0) { f[k] = -con_D[cs] * jr; part[0] += con_D[cs] * jr * jr; }
+          if (jr < 0 && (!DYN || k < con_nrow[cs])) { f[k] = -con_D[cs] * jr; part[0] += con_D[cs] * jr * jr; }
         }
         const float mu = con_mu[cs];
         const float fn = f[0] + f[1] + f[2] + f[3], f1 = mu * (f[0] - f[1]), f2 = mu * (f[2] - f[3]);
@@ -1453,12 +1598,23 @@ struct Wave {
 #pragma unroll
         for (int k = 0; k < 6; ++k) w[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(W[k]), l));
         const int ld = __builtin_amdgcn_readlane(leaf, l);
+        const int ld1 = DYN ? __builtin_amdgcn_readlane(con_leaf1[cs], l) : -1;
 #pragma unroll
         for (int s = 0; s < NVS; ++s) {
-          if (s > 0 && ld < RR_LANES * s) continue;      // wave-uniform: the chain (dofs <= leaf) has no dof in this slot
+          if (s > 0 && ld < RR_LANES * s && ld1 < RR_LANES * s) continue;      // wave-uniform: the chains (dofs <= leaf) have no dof in this slot
           const int d = lane + RR_LANES * s;
-          if (d <= ld && ld <= (opaque(dofc1[s]) >> 16))
-            qc[s] += cd[s][0] * w[0] + cd[s][1] * w[1] + cd[s][2] * w[2] + cd[s][3] * w[3] + cd[s][4] * w[4] + cd[s][5] * w[5];
+          if (!DYN) {
+            if (d <= ld && ld <= (opaque(dofc1[s]) >> 16))
+              qc[s] += cd[s][0] * w[0] + cd[s][1] * w[1] + cd[s][2] * w[2] + cd[s][3] * w[3] + cd[s][4] * w[4] + cd[s][5] * w[5];
+          } else {
+            const int last = opaque(dofc1[s]) >> 16;
+            const bool on2 = d <= ld && ld <= last;
+            const bool on1 = ld1 >= 0 && d <= ld1 && ld1 <= last;          // body1's chain: the force enters with a minus sign
+            if (on2 != on1) {       // a dof on both chains gets +t - t = 0
+              const float t = cd[s][0] * w[0] + cd[s][1] * w[1] + cd[s][2] * w[2] + cd[s][3] * w[3] + cd[s][4] * w[4] + cd[s][5] * w[5];
+              qc[s] += on2 ? t : -t;
+            }
+          }
         }
       }
     }
@@ -1679,7 +1835,7 @@ struct Wave {
         R += 4 * __popcll(m);
         if (con_act[cs]) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) { st_jr[pos + k] = con_jar[cs][k]; st_jv[pos + k] = con_jv[cs][k]; st_D[pos + k] = con_D[cs]; }
+          for (int k = 0; k < 4; ++k) { st_jr[pos + k] = con_jar[cs][k]; st_jv[pos + k] = con_jv[cs][k]; st_D[pos + k] = (!DYN || k < con_nrow[cs]) ? con_D[cs] : 0.0f; }
         }
       }
 #pragma unroll
@@ -1822,7 +1978,7 @@ struct Wave {
     for (int s = 0; s < NVS; ++s) {
       const int d = lane + RR_LANES * s;
       if (d < D.nv) {
-        const int u = T.dof_i[RR_DOFI * d + 7];
+        const int u = DYN ? -1 : T.dof_i[RR_DOFI * d + 7];      // DYN: an actuator may drive several dofs -- integrated per actuator below
         if (u >= 0) {   // filter activation dynamics: act_dot = (clamp(ctrl) - act) / tau
           auto af = T.act_f + 8 * u;
           const float c = fminf(fmaxf(s_ctrl[u], af[5]), af[6]);
@@ -1830,6 +1986,11 @@ struct Wave {
         }
         s_qvel[d] += D.dt * qa[s];
       }
+    }
+    if (DYN && lane < D.nu) {
+      auto af = T.act_f + 8 * lane;
+      const float c = fminf(fmaxf(s_ctrl[lane], af[5]), af[6]);
+      s_act[lane] += D.dt * ((c - s_act[lane]) / fmaxf(af[4], RR_MINVAL));
     }
     sync();
 #pragma unroll
@@ -1966,10 +2127,11 @@ __device__ __forceinline__ void rr_actor_step(const RRIO& io, const DT& D, int l
 // PAIR (see Wave): 128 threads = one wavefront per replica of a two-tree model; Dk / T describe ONE replica (nv_scale = the model's
 // dof count), the state arrays are the model's ([N][2 nq] ...: replica r of environment e is row 2 e + r of an [2 N][nq] array).
 // Physics only (pipeline_init / pipeline_step: no env epilogue, no optional outputs, no debug dump).
-template <int NBS, int NVS, int NCS, bool PROF, bool DBG, class DT, bool NEWTON = false, bool UNROLL = false, bool ACTOR = false, bool PAIR = false>
+template <int NBS, int NVS, int NCS, bool PROF, bool DBG, class DT, bool NEWTON = false, bool UNROLL = false, bool ACTOR = false, bool PAIR = false, bool DYN = false>
 __global__ __launch_bounds__((PAIR ? 2 : 1) * RR_LANES, (NVS >= 3 ? 1 : 2)) void rr_step_kernel(const RRDims Dk, const RRTables T, const RRIO io_kernarg, const int num_envs,
                                                            const int n_frames) {
   static_assert(!PAIR || (!PROF && !DBG && !NEWTON && !UNROLL && !ACTOR), "PAIR: production physics instance only");
+  static_assert(!DYN || (!PROF && !DBG && !NEWTON && !UNROLL && !ACTOR && !PAIR), "DYN: production instance only");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int env = blockIdx.x;
   if (env >= num_envs) return;
@@ -1977,7 +2139,7 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * RR_LANES, (NVS >= 3 ? 1 : 2)) void
   // LDS -- checked on the HOST for every instance a batch may launch (rr_batch_create: hipFuncGetAttributes().sharedSizeBytes == 0)
   const DT D(Dk);
   const int wrep = PAIR ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
-  Wave<NBS, NVS, NCS, DT, NEWTON, PAIR> w(D, T, PAIR ? lds + wrep * (D.lds_bytes_rep >> 2) : lds);
+  Wave<NBS, NVS, NCS, DT, NEWTON, PAIR, DYN> w(D, T, PAIR ? lds + wrep * (D.lds_bytes_rep >> 2) : lds);
   int lane = threadIdx.x & (RR_LANES - 1);
   if (PAIR) { w.rep = wrep; w.s_xc = lds + 2 * (D.lds_bytes_rep >> 2); }
   RRIO io = load_io();
@@ -2126,7 +2288,8 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * RR_LANES, (NVS >= 3 ? 1 : 2)) void
         op = io.o_cpos ? io.o_cpos + (size_t)env * 3 * D.ncon : nullptr;
         of = io.o_cframe ? io.o_cframe + (size_t)env * 9 * D.ncon : nullptr;
       }
-      w.contact_geometry(dg, od, op, of);
+      if (DYN) w.contact_geometry_dyn();
+      else w.contact_geometry(dg, od, op, of);
     }
     w.velocity_sweep();
     w.template stamp<PROF>(2);
@@ -2230,7 +2393,7 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * RR_LANES, (NVS >= 3 ? 1 : 2)) void
   io = load_io();
   if (PROF && io.prof && lane == 0) for (int i = 0; i < RR_NPH; ++i) io.prof[(size_t)env * RR_NPH + i] = w.pt[i];
   if (UNROLL) u_work += (unsigned)w.work;        // a multi-step launch reports the work of all its steps
-  if (io.cost && lane == 0 && wrep == 0) io.cost[env] = UNROLL ? u_work : (unsigned)w.work;
+  if (io.cost && lane == 0 && wrep == 0) io.cost[env] = (UNROLL ? u_work : (unsigned)w.work) | (DYN && w.dyn_overflow ? 0x80000000u : 0u);
   // ---- write back state (a multi-step rollout writes it once, after the wrappers of its last step: see below)
   if (!UNROLL) {
     for (int i = lane; i < D.nq; i += RR_LANES) io.qpos[(size_t)senv * D.nq + i] = w.s_qpos[i];

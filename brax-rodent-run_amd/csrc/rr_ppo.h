@@ -418,15 +418,15 @@ __global__ __launch_bounds__(256) void rr_obs_moments_kernel(const RRMomArgs A) 
   const long long r0 = (long long)blockIdx.x * A.rows_per_block;
   const long long r1 = r0 + A.rows_per_block < A.nrows ? r0 + A.rows_per_block : A.nrows;
   for (int k = threadIdx.x; k < A.K; k += 256) {
-    const float m = A.mean[k];
+    const double m = (double)A.mean[k];
     double s1 = 0.0, s2 = 0.0;
     long long seq = r0 / A.T;
     int t = (int)(r0 - seq * A.T);
     const float* p = A.obs + ((size_t)seq * A.Tp1 + t) * A.K + k;
     for (long long r = r0; r < r1; ++r) {
-      const float d = *p - m;
-      s1 += (double)d;
-      s2 += (double)d * (double)d;
+      const double d = (double)*p - m;      // the difference itself in double: the sums are exact to double round-off
+      s1 += d;
+      s2 += d * d;
       if (++t == A.T) { t = 0; p += (size_t)(A.Tp1 - A.T + 1) * A.K; } else p += A.K;
     }
     A.part[((size_t)blockIdx.x * 2) * A.K + k] = s1;

@@ -79,6 +79,11 @@ def replica_model(m):
     rows("dof_Madr", hv, reb(hM))
     rows("actuator_dofadr", hu, reb(hv)); rows("actuator_gainprm0", hu); rows("actuator_biasprm", hu); rows("actuator_dynprm0", hu)
     rows("actuator_ctrlrange", hu)
+    madr = np.asarray(m["actuator_momentadr"])
+    if np.any(np.diff(madr) != 1):
+        return None                       # joint transmissions only
+    rows("actuator_moment_dofadr", hu, reb(hv)); rows("actuator_moment_qposadr", hu, reb(hq)); rows("actuator_moment_coef", hu)
+    h["actuator_momentadr"] = np.arange(hu + 1, dtype=np.int32)
     # qpos0 / qpos_spring: hinge entries identical, the free joint's 7 are not used by the dynamics
     q0, q1 = np.asarray(m["qpos0"])[:hq].copy(), np.asarray(m["qpos0"])[hq:].copy()
     q1[:7] = q0[:7]
@@ -101,7 +106,7 @@ def replica_model(m):
     sel = [np.nonzero((cb >= 1 + r * hb) & (cb < 1 + (r + 1) * hb))[0] for r in (0, 1)]
     if len(sel[0]) != ncon // 2 or len(sel[1]) != ncon // 2:
         return None
-    for name in ("con_kind", "con_friction", "con_invweight", "con_solref", "con_solimp"):
+    for name in ("con_kind", "con_dim", "con_friction", "con_invweight", "con_solref", "con_solimp"):
         same(np.asarray(m[name])[sel[0]], np.asarray(m[name])[sel[1]], name)
         h[name] = np.asarray(m[name])[sel[0]].copy()
     same(cb[sel[0]], cb[sel[1]] - hb, "con_body2")
@@ -132,9 +137,17 @@ def build_kernel_tables(m):
     dpar = m["dof_parentid"]
     Madr = m["dof_Madr"]
     ddepth = m["dof_depth"]
-    NBS, NVS, NCS = _slots(nb), _slots(nv), _slots(ncon)
+    # DYN models (rodent_cpu.xml): contacts between two moving bodies (sphere / capsule pairs), condim 1 rows,
+    # tendon transmissions.  The contact list is then a list of CANDIDATE pairs: the kernel scans it every substep and keeps the pairs
+    # in penetration in the 64 contact slots of the wave (`rr_step_kernel<..., DYN>`).
+    dyn = bool(ncon and (np.any(np.asarray(m["con_body1"]) != 0) or ("con_dim" in m and np.any(np.asarray(m["con_dim"]) != 3)))) or \
+        bool(np.any(np.diff(np.asarray(m["actuator_momentadr"])) != 1))
+    if dyn and ncon and not np.all(np.isin(np.asarray(m["con_kind"]), (4, 5, 6))):
+        raise ValueError("a model with contacts between moving bodies must have only sphere / capsule pairs (no floor contacts) on the HIP path")
+    NBS, NVS, NCS = _slots(nb), _slots(nv), (1 if dyn else _slots(ncon))
     k = {}
     k["k_slots"] = np.array([NBS, NVS, NCS], np.int32)
+    k["k_dyn"] = np.int32(dyn)
 
     depth = m["body_depth"]
     nlevel = int(depth.max())
@@ -192,11 +205,22 @@ def build_kernel_tables(m):
         else:
             kind[d] = 6
             dof_qposadr[d] = m["jnt_qposadr"][j]
+    # transmission [UP mjx smooth.transmission]: actuator u acts on the dofs of its moment entries with coefficients (a joint: one entry,
+    # coefficient 1; a fixed tendon: its joints).  Per dof: the one actuator that drives it and its coefficient.
+    act_coef = np.zeros(nv)
+    madr = np.asarray(m["actuator_momentadr"])
     for u in range(int(m["nu"])):
-        d = m["actuator_dofadr"][u]
-        if act_of_dof[d] >= 0:
-            raise ValueError("two actuators on one dof are not supported")
-        act_of_dof[d] = u
+        for e in range(int(madr[u]), int(madr[u + 1])):
+            d = int(m["actuator_moment_dofadr"][e])
+            if act_of_dof[d] >= 0:
+                raise ValueError("two actuators on one dof are not supported")
+            act_of_dof[d] = u
+            act_coef[d] = float(m["actuator_moment_coef"][e])
+    k["k_act_i"] = np.stack([madr[:-1], np.diff(madr)], axis=1).astype(np.int32)                      # first moment entry, count
+    k["k_act_m_i"] = np.stack([m["actuator_moment_dofadr"], m["actuator_moment_qposadr"]], axis=1).astype(np.int32)
+    k["k_act_m_f"] = np.asarray(m["actuator_moment_coef"], np.float64)
+    if int(np.diff(madr).max()) > 16:
+        raise ValueError("more than 16 joints in one tendon transmission")
     lim = np.zeros(nv, np.int32)
     for j in range(njnt):
         if m["jnt_limited"][j]:
@@ -220,7 +244,7 @@ def build_kernel_tables(m):
         np.where(hinge, m["qpos_spring"][dof_qposadr], 0.0),
         m["jnt_range"][jid, 0], m["jnt_range"][jid, 1], m["jnt_solref"][jid, 0], m["jnt_solref"][jid, 1],
         m["jnt_solimp"][jid, 0], m["jnt_solimp"][jid, 1], m["jnt_solimp"][jid, 2], m["jnt_solimp"][jid, 3],
-        m["jnt_solimp"][jid, 4], m["dof_invweight0"], np.zeros(nv), np.zeros(nv)], axis=1)         # 16 floats
+        m["jnt_solimp"][jid, 4], m["dof_invweight0"], act_coef, np.zeros(nv)], axis=1)         # 16 floats
     nu = int(m["nu"])
     k["k_act_f"] = np.stack([m["actuator_gainprm0"], m["actuator_biasprm"][:, 0], m["actuator_biasprm"][:, 1],
                              m["actuator_biasprm"][:, 2], m["actuator_dynprm0"], m["actuator_ctrlrange"][:, 0],
@@ -393,6 +417,9 @@ def build_kernel_tables(m):
 
     # ---- contacts
     WC = NCS * LANES
+    if dyn:
+        _pair_tables(m, k, anc, anc_adr, ddepth, last_desc)
+        return k
     g2 = m["con_geom2"]
     g1 = m["con_geom1"]
     body = m["con_body2"]
@@ -434,3 +461,44 @@ def build_kernel_tables(m):
             rows9[c, p // 4] |= int(chain_tab[p, c]) << (8 * (p % 4))
     k["k_con_chain_rows"] = (rows9 & 0xFFFFFFFF).astype(np.uint32).view(np.int32).reshape(-1)
     return k
+
+
+def _pair_tables(m, k, anc, anc_adr, ddepth, last_desc):
+    """Candidate-pair tables of a DYN model (two moving geoms per contact): per pair 8 ints (kind, body1, body2, tree, signed-chain length,
+    last dof of body1, last dof of body2, rows: 1 = frictionless, 4 = pyramid), 32 floats (geom1 local pos / quat / size, geom2 the same,
+    mu, effective invweight, solref, solimp), and the SIGNED dof chain of J = jac(body2) - jac(body1): the dofs on exactly one of the
+    two ancestor chains, id | 128 for body1's (they enter with a minus sign), padded with nv (a zero motion vector), 40 ids = 10 ints."""
+    ncon, nv = int(m["ncon"]), int(m["nv"])
+    if nv >= 128:
+        raise ValueError("signed dof ids need nv < 128")
+    ld = np.asarray(m["body_lastdof"])
+    g1, g2 = np.asarray(m["con_geom1"]), np.asarray(m["con_geom2"])
+    b1, b2 = np.asarray(m["con_body1"]), np.asarray(m["con_body2"])
+    mu = np.asarray(m["con_friction"])[:, 0]
+    dim = np.asarray(m["con_dim"])
+    invw = np.where(dim == 1, m["con_invweight"], (m["con_invweight"] + mu * mu * m["con_invweight"]) * 2 * mu * mu / float(m["opt_impratio"]))
+    pi = np.zeros((ncon, 8), np.int32)
+    rows10 = np.full((ncon + 1, 40), nv, np.int64)
+    root = k["k_body_root"]
+    for c in range(ncon):
+        def chain(b):
+            d = int(ld[b])
+            return [int(x) for x in anc[anc_adr[d]:anc_adr[d + 1]]] if d >= 0 else []
+        c1, c2 = chain(b1[c]), chain(b2[c])
+        s1, s2 = set(c1), set(c2)
+        sig = [d for d in c2 if d not in s1] + [d | 128 for d in c1 if d not in s2]
+        if len(sig) > 40:
+            raise ValueError("contact chains longer than 40 dofs are not supported by the kernel")
+        rows10[c, :len(sig)] = sig
+        pi[c] = (m["con_kind"][c], b1[c], b2[c], root[b2[c]], len(sig), ld[b1[c]], ld[b2[c]], 1 if dim[c] == 1 else 4)
+        if root[b1[c]] != root[b2[c]]:
+            raise ValueError("contacts between two kinematic trees are not supported")
+    k["k_con_i"] = pi
+    k["k_con_f"] = np.concatenate([
+        m["geom_pos"][g1], m["geom_quat"][g1], m["geom_size"][g1], m["geom_pos"][g2], m["geom_quat"][g2], m["geom_size"][g2],
+        mu[:, None], invw[:, None], m["con_solref"].reshape(ncon, 2), m["con_solimp"].reshape(ncon, 5), np.zeros((ncon, 3))], axis=1)   # 32 floats
+    packed = np.zeros((ncon + 1, 10), np.int64)
+    for j in range(40):
+        packed[:, j // 4] |= rows10[:, j] << (8 * (j % 4))
+    k["k_con_chain_rows"] = (packed & 0xFFFFFFFF).astype(np.uint32).view(np.int32).reshape(-1)
+    k["k_con_chain_packed"] = np.zeros((9, LANES), np.int32)        # (static-slot table of the floor-contact instances: unused)

@@ -577,7 +577,11 @@ def compile_mjcf(xml_path: str, *, iterations: int = 6, ls_iterations: int = 6,
     # the fused HIP kernel serves the floor-contact, joint-actuated, free-floating rodents; other models (rodent_cpu.xml:
     # tendon transmissions, welded root) compile for the CPU path only and their blob carries no kernel tables, so
     # rr_model_load refuses them
-    hip_ok = (not any(trn_type)) and int(m["ncon"]) > 0 and any(t == FREE for t in jnt_type) and not np.any(m["con_body1"] != 0) and not np.any(m["con_dim"] != 3)
+    # floor-contact rodents: the fused static-slot instances; models with contacts between moving bodies / condim 1 / tendon transmissions
+    # (rodent_cpu.xml): the DYN instance, sphere / capsule pairs only (ktables.build_kernel_tables decides and checks)
+    floor_model = (not any(trn_type)) and any(t == FREE for t in jnt_type) and not np.any(m["con_body1"] != 0) and not np.any(m["con_dim"] != 3)
+    dyn_model = int(m["ncon"]) > 0 and bool(np.all(np.isin(m["con_kind"], (4, 5, 6))))
+    hip_ok = int(m["ncon"]) > 0 and (floor_model or dyn_model)
     m["hip_supported"] = np.int32(hip_ok)
     if hip_ok:
         from .ktables import build_kernel_tables, replica_model

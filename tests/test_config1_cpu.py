@@ -6,8 +6,7 @@ sphere-capsule, capsule-capsule, condim 1 and 3; tests/test_self_collision_cpu.p
 stay dropped (count kept in the blob).  What is exercised here: the MJCF compiler on that file (dims, tendon
 transmission tables), the env reset / step arithmetic on the CPU oracle for 4 envs (shapes, finite outputs, determinism, joint limits
 active), the tendon transmission in BOTH CPU formulations (C oracle: sparse entries; np_ref: dense moment matrix), and that the HIP
-library refuses this model instead of mis-running it (contacts between two moving bodies and tendon transmissions have no kernel
-instance: the J-free products of the step kernel walk ONE ancestor chain per contact).  The env's `qpos[:3] = track_pos` and `q[2]`
+library loads this model for its candidate-pair (DYN) instance (the GPU side: tests/test_gpu_self_collision.py).  The env's `qpos[:3] = track_pos` and `q[2]`
 health test act on hinge angles here, exactly as the reference code would."""
 import os
 
@@ -23,7 +22,7 @@ from tests.oracle_env import OracleRodent
 def test_compiled_dims_and_tendon_tables():
     m = mjcf.load_blob(assets.asset_path("rodent_cpu"))
     got = {k: int(m[k]) for k in ("nbody", "nq", "nv", "nu", "ngeom", "nM", "ntendon", "ncon", "nlimit", "hip_supported")}
-    assert got == dict(nbody=66, nq=67, nv=67, nu=38, ngeom=100, nM=696, ntendon=8, ncon=2243, nlimit=67, hip_supported=0)
+    assert got == dict(nbody=66, nq=67, nv=67, nu=38, ngeom=100, nM=696, ntendon=8, ncon=2243, nlimit=67, hip_supported=1)
     assert int(m["ncon"]) + int(m["ndropped_pairs"]) == 4271
     adr = m["actuator_momentadr"]
     assert (np.diff(adr)[:8] == [2, 2, 2, 3, 2, 2, 12, 12]).all() and (np.diff(adr)[8:] == 1).all()      # [REF models/rodent_cpu.xml:505-560]
@@ -71,6 +70,20 @@ def test_tendon_transmission_in_both_formulations(oracle_built):
         assert np.count_nonzero(c.get("qfrc_actuator")) > 38          # tendon actuators spread over several dofs
 
 
-def test_hip_library_refuses_the_model():
-    with pytest.raises(RuntimeError, match="blob lacks"):
-        hip.Model(assets.asset_path("rodent_cpu"))
+def test_hip_library_loads_the_model_as_a_candidate_pair_model():
+    """Round 3: the blob carries kernel tables for the DYN instance (candidate pairs of two moving geoms, tendon transmissions); the
+    host half of the C ABI loads it without a GPU.  The solvers / diagnostics that instance does not have are refused loudly."""
+    m = hip.Model(assets.asset_path("rodent_cpu"), 6, 6)
+    d = m.dims
+    assert (d.nq, d.nv, d.nu, d.nbody, d.ncon, d.obs_dim) == (67, 67, 38, 66, 2243, 1244) and d.lds_bytes <= 20480
+    tab = mjcf.load_blob(assets.asset_path("rodent_cpu"))
+    assert int(tab["k_dyn"]) == 1 and tab["k_con_i"].shape == (2243, 8) and tab["k_con_f"].shape == (2243, 32)
+    # signed chains: every id is a dof (bit 7 = body1's side) or the padding id nv; never a dof on both sides
+    rows = tab["k_con_chain_rows"].view(np.uint32).reshape(-1, 10)[:-1]
+    ids = np.stack([(rows[:, j // 4] >> (8 * (j % 4))) & 255 for j in range(40)], axis=1)
+    nsig = tab["k_con_i"][:, 4]
+    for c in (0, 500, 2242):
+        used = ids[c, :nsig[c]]
+        assert np.all((used & 127) < 67) and len(set((used & 127).tolist())) == nsig[c] and np.all(ids[c, nsig[c]:] == 67)
+    with pytest.raises(RuntimeError, match="Newton"):
+        hip.Model(assets.asset_path("rodent_cpu"), 6, 6, solver="newton")

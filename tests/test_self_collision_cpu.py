@@ -79,7 +79,7 @@ def test_compiled_contact_tables():
     key = [(int(gt[a]), int(gt[b]), int(a), int(b)) for a, b in zip(tab["con_geom1"], tab["con_geom2"])]
     assert key == sorted(key) and all(k[0] <= k[1] for k in key)
     assert np.all(tab["con_body1"] > 0) and np.all(tab["con_body1"] != tab["con_body2"])
-    assert int(tab["hip_supported"]) == 0
+    assert int(tab["hip_supported"]) == 1 and int(tab["k_dyn"]) == 1
 
 
 def test_two_formulations_agree_on_colliding_states(colliding_states):
