@@ -130,8 +130,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5), help="BASELINE.json config (2 = the headline metric's)")
-    ap.add_argument("--num-envs", type=int, default=None, help="envs per GPU (default 2048; 4096 for config 5)")
+    ap.add_argument("--config", type=int, default=2, choices=(1, 2, 3, 5), help="BASELINE.json config (2 = the headline metric's; 1 = Rodent.step, 4 envs, rodent_cpu.xml)")
+    ap.add_argument("--num-envs", type=int, default=None, help="envs per GPU (default 2048; 4096 for config 5; 4 for config 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--substreams", type=int, default=1, help="config 2: the envs of a GPU are stepped as this many sub-batches on separate "
                     "HIP streams (one sub-batch's slowest envs overlap the others' bulk); 1 = one launch per step")
@@ -153,7 +153,7 @@ def parse():
     args.steps = dflt[0] if args.steps is None else args.steps
     args.warmup = dflt[1] if args.warmup is None else args.warmup
     if args.num_envs is None:
-        args.num_envs = 4096 if args.config == 5 else NUM_ENVS
+        args.num_envs = 4096 if args.config == 5 else (4 if args.config == 1 else NUM_ENVS)
     return args
 
 
@@ -254,7 +254,7 @@ def main():
     from rodent_amd.envs import wrappers
 
     N = args.num_envs
-    model = "rodent_pair" if args.config == 5 else MODEL
+    model = "rodent_pair" if args.config == 5 else ("rodent_cpu" if args.config == 1 else MODEL)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -310,6 +310,30 @@ def main():
                 st_ = env.step(st_, torch.empty(N, env.action_size, device=dev).uniform_(-1.0, 1.0, generator=gen))
             torch.cuda.synchronize(dev)
             extra["step_kernel_time_source"] = "host-issued pass of 30 steps after training (rollouts are HIP-graph replays of sub-batches)"
+    elif args.config == 1:
+        # ---- BASELINE config 1: Rodent.step() with num_envs = 4 on rodent_cpu.xml (self-collisions between sphere / capsule pairs, tendon
+        # transmissions, no floor / free joint) through the DYN kernel instance; plumbing-sized: 4 waves on the whole GPU, launch-latency bound
+        env = envs.get_environment("rodent", track_pos=synthetic_track(), num_envs=N, xml_path=f"{model}.xml", terminate_when_unhealthy=True,
+                                   solver="cg", iterations=6, ls_iterations=6, device=dev)
+        wenv = wrappers.wrap(env, episode_length=150, action_repeat=1)
+        state = wenv.reset(jax_random.split(jax_random.fold_in(jax_random.PRNGKey(0), rank), N))
+        nu = env.action_size
+        batch = env._batch
+        workload = f"{model}.xml Rodent.step through Episode(150)+AutoReset wrappers, {N} envs, CG 6/6, n_frames 10, random actions (DYN instance)"
+        for _ in range(args.warmup):
+            state = wenv.step(state, torch.empty(N, nu, device=dev).uniform_(-1.0, 1.0, generator=gen))
+        batch.set_timing(True)
+        repeats_ms = []
+        for rep in range(args.repeats):
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                state = wenv.step(state, torch.empty(N, nu, device=dev).uniform_(-1.0, 1.0, generator=gen))
+            fence()
+            repeats_ms.append(max_over_ranks(time.perf_counter() - t0) / args.steps * 1e3)
+        assert torch.isfinite(state.obs).all(), "non-finite state in the rollout"
+        total_env_steps = N * world * args.steps
+        elapsed = float(np.median(repeats_ms)) * args.steps * 1e-3
     else:
         if args.config == 2:
             # The N envs of this GPU are stepped as S sub-batches of N / S envs, each with its own batch, stream, wrapper state and

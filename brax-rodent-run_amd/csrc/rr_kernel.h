@@ -2444,8 +2444,10 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * RR_LANES, (NVS >= 3 ? 1 : 2)) void
       if (lane == 0) {
         int fi = old_frame < 0 ? 0 : (old_frame > io.track_len - 1 ? io.track_len - 1 : old_frame);
         const v3 dx = ld3(w.s_qpos) - ld3(io.track_pos + 3 * fi);
-        // explicit roundings (no fused multiply-add left to the optimiser): every instance of the kernel -- single step, multi-step,
-        // actor inside -- must form the reward identically, bit for bit
+        // explicit roundings (no fused multiply-add left to the optimiser), so that the instances of the kernel form the reward from the
+        // same operations: single-step and multi-step instances agree bit for bit (tests/test_gpu_env.py); the actor-inside instance to
+        // ONE ulp -- `expf` below is expanded inline per instance and its expansion there rounds differently
+        // (tests/test_gpu_ppo.py::test_one_launch_unroll_with_the_actor_inside allows exactly that)
         const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx.x, dx.x), __fmul_rn(dx.y, dx.y)), __fmul_rn(dx.z, dx.z));
         const float pos_reward = expf(__fmul_rn(-100.0f, sqrtf(d2)));
         const float z = w.s_qpos[2];
