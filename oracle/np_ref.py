@@ -3,8 +3,10 @@
 Purpose: pin `oracle/rodent_ref.c` (and the model compiler's `mj_setConst` constants) by a different
 formulation of the same physics, so that an error shared by the C oracle and the HIP kernel -- both
 follow MuJoCo's composite-rigid-body / spatial-vector-about-the-subtree-COM organisation -- cannot hide.
-PARITY STAYS UNPINNED AGAINST THE REFERENCE ITSELF: mujoco / mujoco-mjx / brax are absent (SURVEY.md 8(c));
-this file pins the oracle against textbook rigid-body dynamics, not against MJX.
+Pinned to the reference only for the forward pass up to the observation (kinematics, COM, cinert, cvel, actuation: the stored
+`mjx.forward` vector of [NB Env_step.ipynb cell 8], tests/test_reference_pin.py); for everything past it PARITY STAYS UNPINNED
+AGAINST THE REFERENCE ITSELF: mujoco / mujoco-mjx / brax are absent; this file pins the oracle against textbook
+rigid-body dynamics, not against MJX.
 
 What is formulated differently here (float64 numpy, dense everywhere, as MJX does with
 `opt.jacobian = 0` [REF Rodent_Env_Brax.py:49]):

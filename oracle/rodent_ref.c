@@ -6,8 +6,12 @@
  * reset/step/obs arithmetic [REF Rodent_Env_Brax.py:71-162].  The MJX/MuJoCo sources are not
  * in /root/reference and the packages (mujoco 3.1.x-3.2.x, mujoco-mjx, brax 0.10-0.11, unpinned)
  * are not installed, so the arithmetic follows the published algorithm (MuJoCo "Computation"
- * chapter) -- PARITY UNPINNED against the reference itself; pinned only by
- * the structural known-answers of the reference notebooks (tests/test_known_answers.py).
+ * chapter).  PINNED to the reference for the forward pass up to the observation:
+ * kinematics, subtree COM, cinert, cvel and actuation agree with the one full vector the reference stores
+ * (its own mjx.forward output, [NB Env_step.ipynb cell 8]; tests/test_reference_pin.py), next to the structural
+ * known-answers of the notebooks (tests/test_known_answers.py).  PARITY UNPINNED for everything past it --
+ * mass matrix, bias forces, contacts (incl. the sphere / capsule primitives, restated from memory), the solver,
+ * the integrator: the reference holds no step() output; those stages rest on oracle/np_ref.py's independent formulation.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  *

@@ -222,3 +222,34 @@ def test_running_statistics_from_sums_equals_the_upstream_form():
     c = running_statistics.update_from_unroll_buffer(a, buf, 5)
     d_ = running_statistics.update(a, buf[:, :, :5])
     torch.testing.assert_close(c.mean, d_.mean); torch.testing.assert_close(c.std, d_.std)
+
+
+def test_checkpoint_callback_round_trip(tmp_path):
+    """The launcher's `policy_params_fn` contract [REF brax_rodent_run_ppo.py:135-139, 204-205]: called as
+    (num_steps, make_policy, params) after every evaluation with params = (normalizer_params, policy_params); `model.save_params` /
+    `load_params` carry exactly what the deterministic policy needs -- the reloaded parameters reproduce the actions bit for bit --
+    and the snapshot a callback received is not changed by later training steps."""
+    from rodent_amd.io import model
+    calls = []
+
+    def policy_params_fn(num_steps, make_policy, params):
+        path = str(tmp_path / f"{num_steps}")
+        model.save_params(path, params)
+        obs = torch.linspace(-1, 1, 5 * 4).reshape(5, 4)
+        act, _ = make_policy(params, deterministic=True)(obs, None)
+        calls.append((num_steps, path, obs, act.clone(), params))
+
+    make_policy, params, _ = ppo.train(environment=PointEnv(16), num_timesteps=16 * 5 * 2 * 4, episode_length=20, num_envs=16, batch_size=16,
+                                       num_minibatches=2, unroll_length=5, num_updates_per_batch=2, num_evals=3, num_eval_envs=8,
+                                       normalize_observations=True, seed=2, policy_params_fn=policy_params_fn)
+    assert len(calls) >= 2 and [c[0] for c in calls] == sorted(c[0] for c in calls) and calls[-1][0] >= 16 * 5 * 2 * 4
+    for num_steps, path, obs, act, snap in calls:
+        norm, sd = model.load_params(path)
+        net = networks.make_ppo_networks(4, 2).policy_network
+        net.load_state_dict(sd)
+        got, _ = make_policy((norm, net), deterministic=True)(obs, None)
+        assert torch.equal(got, act)                                       # the checkpoint reproduces the policy
+        again, _ = make_policy(snap, deterministic=True)(obs, None)
+        assert torch.equal(again, act)                                     # the callback's snapshot did not move with training
+        assert float(norm.count) == float(snap[0].count)
+    assert not torch.equal(calls[0][3], calls[-1][3])                      # training did change the policy in between
