@@ -261,6 +261,7 @@ struct rr_batch {
   const int32_t* env_map = nullptr;     // rr_batch_set_schedule
   uint32_t* cost = nullptr;
   bool counted = false;                 // this batch is in m->live_batches
+  unsigned* dyn_overflow = nullptr;     // DYN models: launches x envs in which more pairs penetrated than the wave has contact slots (rr_batch_contact_overflow)
   unsigned* progress = nullptr;         // pacing counter of multi-step launches (RRIO::progress); RR_PACE=0 turns pacing off
 };
 
@@ -395,6 +396,13 @@ extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t devi
     if (e != hipSuccess) { rr_batch_destroy(b); return fail(RR_EHIP, std::string("hipFuncGetAttributes: ") + hipGetErrorString(e)); }
     if (fa.sharedSizeBytes != 0) { rr_batch_destroy(b); return fail(RR_EUNSUPPORTED, "rr_batch_create: a step-kernel instance has static LDS (the level schedules need the dynamic segment at address 0)"); }
   }
+  if (m->dyn) {
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, 64));
+    HIPCHK(hipMemset(p, 0, 64));
+    b->dev_allocs.push_back(p);
+    b->dyn_overflow = (unsigned*)p;
+  }
   {
     const char* pace = getenv("RR_PACE");
     if (!(pace && pace[0] == '0')) {
@@ -504,6 +512,7 @@ static int launch(rr_batch* b, const rr_state* st, const float* ctrl, int n_fram
   if (!kern) return fail(RR_EUNSUPPORTED, "launch: no diagnostic kernel instance for this model");
   io.prof = b->prof;
   io.env_map = b->env_map; io.cost = b->cost;
+  io.dyn_overflow = b->dyn_overflow;
   RRDims kd = b->kd;
   kd.iterations = b->m->kd.iterations; kd.ls_iterations = b->m->kd.ls_iterations;
   // two-tree model, physics only, no diagnostics: one wavefront per replica (rr_kernel.h PAIR)
@@ -536,6 +545,17 @@ extern "C" int rr_env_step_to(rr_batch* b, const rr_state* in, const rr_state* o
   if (!env) return fail(RR_EINVAL, "rr_env_step_to: env io required");
   if (!in || !cur_frame_in) return fail(RR_EINVAL, "rr_env_step_to: null input state");
   return launch(b, outst, action, n_frames, env, out, 1, in, cur_frame_in);
+}
+extern "C" int rr_batch_contact_overflow(rr_batch* b, int64_t* events) {
+  if (!b || !events) return fail(RR_EINVAL, "rr_batch_contact_overflow: null argument");
+  *events = 0;
+  if (!b->dyn_overflow) return RR_OK;                // static-slot models hold every contact of the model: nothing can overflow
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  unsigned v = 0;
+  HIPCHK(hipMemcpy(&v, b->dyn_overflow, sizeof(v), hipMemcpyDeviceToHost));
+  *events = (int64_t)v;
+  return RR_OK;
 }
 extern "C" int rr_batch_unroll_supported(const rr_batch* b, int32_t with_actor) {
   if (!b) return fail(RR_EINVAL, "rr_batch_unroll_supported: null batch");

@@ -173,6 +173,7 @@ struct RRIO {
   // its wave priority (Wave::env_prio): the launch ends when its SLOWEST environment does, and a wave that outranks its SIMD partner
   // runs at close to single-wave speed while the partner, which is ahead, has slack.  Timing only -- results are unaffected.
   unsigned* progress;
+  unsigned* dyn_overflow;            // DYN instances (nullable): counts (env, substep) events with more pairs in penetration than contact slots
   float pace_t1, pace_t2, pace_t3;   // env steps behind the average for priority levels 1, 2, 3
   int pace_mode;                     // bits 0-1: 0 max(weight level, lag level), 1 lag level only, 2 sum capped at 3; bit 2 (4): progress counted
                                      // per SUBSTEP (ten times finer); bit 3 (8): the factor-phase priority is 3 for laggards, 2 otherwise
@@ -1369,7 +1370,7 @@ struct Wave {
       }
       count += __popcll(mk);
     }
-    dyn_overflow = count > WC ? 1 : 0;
+    dyn_overflow |= count > WC ? 1 : 0;
     if (count > WC) count = WC;
     sync();
 #pragma unroll
@@ -2394,6 +2395,7 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * RR_LANES, (NVS >= 3 ? 1 : 2)) void
   if (PROF && io.prof && lane == 0) for (int i = 0; i < RR_NPH; ++i) io.prof[(size_t)env * RR_NPH + i] = w.pt[i];
   if (UNROLL) u_work += (unsigned)w.work;        // a multi-step launch reports the work of all its steps
   if (io.cost && lane == 0 && wrep == 0) io.cost[env] = (UNROLL ? u_work : (unsigned)w.work) | (DYN && w.dyn_overflow ? 0x80000000u : 0u);
+  if (DYN && w.dyn_overflow && io.dyn_overflow && lane == 0) __hip_atomic_fetch_add(io.dyn_overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // ---- write back state (a multi-step rollout writes it once, after the wrappers of its last step: see below)
   if (!UNROLL) {
     for (int i = lane; i < D.nq; i += RR_LANES) io.qpos[(size_t)senv * D.nq + i] = w.s_qpos[i];

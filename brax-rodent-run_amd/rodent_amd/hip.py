@@ -64,7 +64,7 @@ class RRPpoCfg(C.Structure):
 
 
 EXPORTS = ["rr_model_load", "rr_model_dims", "rr_model_set_solver", "rr_model_set_solver_type", "rr_model_destroy", "rr_model_table", "rr_kernarg_layout", "rr_batch_create",
-           "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset", "rr_pipeline_step_to", "rr_env_step_to", "rr_batch_unroll_supported", "rr_env_unroll", "rr_env_unroll_policy",
+           "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset", "rr_pipeline_step_to", "rr_env_step_to", "rr_batch_contact_overflow", "rr_batch_unroll_supported", "rr_env_unroll", "rr_env_unroll_policy",
            "rr_compute_gae", "rr_mlp_forward", "rr_ppo_loss_workspace_bytes", "rr_ppo_loss", "rr_policy_act_workspace_bytes", "rr_policy_act", "rr_policy_sample", "rr_policy_backward_workspace_bytes", "rr_policy_backward", "rr_mlp_silu_backward_workspace_bytes", "rr_mlp_silu_backward", "rr_mlp_value_backward_workspace_bytes", "rr_mlp_value_backward", "rr_mlp_weight_grad_workspace_bytes", "rr_mlp_weight_grad", "rr_mlp_weight_grad_batch_workspace_bytes", "rr_mlp_weight_grad_batch", "rr_obs_moments_workspace_bytes", "rr_obs_moments", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_schedule", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
 
 _lib = None
@@ -97,6 +97,7 @@ def lib():
         L.rr_env_step_to.argtypes = [C.c_void_p, C.POINTER(RRState), C.POINTER(RRState), C.c_void_p, C.c_int32, C.POINTER(RREnvIO),
                                      C.c_void_p, C.POINTER(RROutputs)]
         L.rr_batch_unroll_supported.argtypes = [C.c_void_p, C.c_int32]
+        L.rr_batch_contact_overflow.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.rr_env_unroll.argtypes = [C.c_void_p, C.POINTER(RRState), C.POINTER(RRState), C.c_void_p, C.c_int32, C.c_int32, C.POINTER(RREnvIO),
                                     C.c_void_p, C.POINTER(RRUnrollIO)]
         L.rr_env_unroll_policy.argtypes = [C.c_void_p, C.POINTER(RRState), C.POINTER(RRState), C.c_int32, C.c_int32, C.POINTER(RREnvIO), C.c_void_p,
@@ -287,6 +288,12 @@ class Batch:
         _check(lib().rr_env_step_to(self.h, C.byref(self._state(st_in)), C.byref(self._state(st_out)),
                                     _ptr(action, numel=self.N * self.dims.nu), int(n_frames), C.byref(self._env(env)),
                                     _ptr(cur_frame_in, torch.int32, self.N), C.byref(o) if o else None))
+
+    def contact_overflow(self) -> int:
+        """(launch, env) events with more pairs in penetration than contact slots (candidate-pair models; synchronises the stream)."""
+        n = C.c_int64()
+        _check(lib().rr_batch_contact_overflow(self.h, C.byref(n)))
+        return int(n.value)
 
     def unroll_supported(self, with_actor: bool = False) -> bool:
         return _check(lib().rr_batch_unroll_supported(self.h, int(with_actor))) == 1

@@ -135,6 +135,12 @@ int rr_env_step_to(rr_batch* b, const rr_state* in, const rr_state* out_state, c
  * written); `wrap`: the stored first state and first observation (restored where an episode ends), the wrappers' state before the
  * launch (prev_done, steps_in [N]) and after it (steps_out, truncation_out [N]; the final done goes to env->done).
  * Production instance only (no rr_outputs); RR_EUNSUPPORTED for models without a multi-step instance and for the Newton solver. */
+/* Models whose contact list is a list of candidate pairs (contacts between two moving bodies, e.g. rodent_cpu.xml [REF models/rodent_cpu.xml]):
+ * the kernel keeps the pairs in penetration in 64 contact slots per environment; pairs beyond that are DROPPED for that substep.  *events = the
+ * number of (launch, environment) events in which that happened since the batch was created (synchronises the batch's stream); always 0 for
+ * the floor-contact models, whose every contact has its own slot. */
+int rr_batch_contact_overflow(rr_batch* b, int64_t* events);
+
 /* 1 when this batch's model / solver has a multi-step kernel instance (with_actor != 0: the one with the actor inside), else 0. */
 int rr_batch_unroll_supported(const rr_batch* b, int32_t with_actor);
 typedef struct rr_unroll_io {

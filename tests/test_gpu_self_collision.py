@@ -50,6 +50,30 @@ def test_teacher_forced_substeps_with_self_collisions(oracle_built):
     out = parity.substep_ladder(NoDiscrete(HipImpl("rodent_cpu", N, (8, 8), False), A), seq, A, B)
     print(out["quantiles"])
     parity.check_quantiles(out["quantiles"], parity.SUBSTEP_FLOORS)
+    assert impl.batch.contact_overflow() == 0                # never more than 64 pairs in penetration: nothing was dropped
+
+
+def test_contact_slot_overflow_is_counted(oracle_built):
+    """A pose with every joint at the same end of its range folds the animal into itself: if more than 64 pairs penetrate, the surplus is
+    dropped for that substep and the batch's overflow counter says so (the state stays finite either way)."""
+    N = 4
+    tab = mjcf.load_blob(assets.asset_path("rodent_cpu"))
+    impl = HipImpl("rodent_cpu", N, (8, 8), False)
+    M = oracle_built.RefModel(assets.asset_path("rodent_cpu"), "f64")
+    d = oracle_built.RefData(M)
+    worst, q_worst = 0, None
+    for sgn in (0, 1):
+        q = np.where(np.arange(67) % 2 == sgn, tab["jnt_range"][:, 0], tab["jnt_range"][:, 1]).astype(np.float64) * 0.98
+        d.init(q, np.zeros(67))
+        n = int((d.get("con_dist") < 0).sum())
+        if n > worst:
+            worst, q_worst = n, q
+    st = dict(qpos=np.tile(q_worst, (N, 1)), qvel=np.zeros((N, 67)), act=np.zeros((N, 38)), qacc_warmstart=np.zeros((N, 67)))
+    ds = impl._dev(st)
+    impl.batch.pipeline_step(ds, torch.zeros(N, 38, device=DEV), 1)
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(v).all() for v in ds.values())
+    assert (impl.batch.contact_overflow() > 0) == (worst > 64), (worst, impl.batch.contact_overflow())
 
 
 def test_contacts_act_and_results_are_deterministic(oracle_built):
