@@ -47,7 +47,8 @@ def test_teacher_forced_substeps_with_self_collisions(oracle_built):
     B = parity.OracleImpl("rodent_cpu", N, "f32", (8, 8))
     nact = sum(int((A.substep(st, c)["con_dist"] < 0).sum()) for st, c in seq[:10])
     assert nact >= 20                                       # the sample does exercise the contacts
-    out = parity.substep_ladder(NoDiscrete(HipImpl("rodent_cpu", N, (8, 8), False), A), seq, A, B)
+    impl = HipImpl("rodent_cpu", N, (8, 8), False)
+    out = parity.substep_ladder(NoDiscrete(impl, A), seq, A, B)
     print(out["quantiles"])
     parity.check_quantiles(out["quantiles"], parity.SUBSTEP_FLOORS)
     assert impl.batch.contact_overflow() == 0                # never more than 64 pairs in penetration: nothing was dropped
