@@ -194,6 +194,9 @@ __device__ __forceinline__ void rr_mlp_store_pol(float* actP, const rr_f4& ap, c
 #ifndef RR_MLP_FWD_WGS
 #define RR_MLP_FWD_WGS 3
 #endif
+#ifndef RR_MLP_RCP
+#define RR_MLP_RCP 0         // 1: multiply by a refined reciprocal instead of dividing -- measured 0.443 vs 0.446-0.450 ms, within noise, so the IEEE division (what the reference computes) stays
+#endif
 #ifndef RR_MLP_STAGES
 #define RR_MLP_STAGES 1      // register stages of layer 1's chunks (2: chunk c+2 in flight during chunk c; needs more than 168 VGPRs)
 #endif
@@ -256,7 +259,16 @@ __global__ __launch_bounds__(256, RR_MLP_FWD_WGS) void rr_mlp_forward_kernel(con
 #pragma unroll
         for (int i = 0; i < RRStage<RR_MLP_BM>::PER; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) S.gx.r[i][j] = (S.gx.r[i][j] - S.mu[i][j]) / S.sd[i][j];
+          for (int j = 0; j < 4; ++j) {
+#if RR_MLP_RCP
+            // (x - mean) * (1 / std), the reciprocal by v_rcp_f32 + one Newton step (<= 1 ulp from the quotient): the IEEE division was 11 of
+            // the ~22 vector instructions per staged element-quad of this loop, on the critical path between two barriers
+            const float r0 = __builtin_amdgcn_rcpf(S.sd[i][j]);
+            S.gx.r[i][j] = (S.gx.r[i][j] - S.mu[i][j]) * (r0 * (2.0f - S.sd[i][j] * r0));
+#else
+            S.gx.r[i][j] = (S.gx.r[i][j] - S.mu[i][j]) / S.sd[i][j];
+#endif
+          }
       }
       S.gx.commit(sX);
       if (has_val) S.gv.commit(sW);
