@@ -46,3 +46,29 @@ def test_env_reset_obs_matches_the_notebook_vector():
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
     open(os.path.join(out, "reference_pin_hip.txt"), "w").write(text + "\n")
+
+
+def test_contact_geometry_matches_the_notebook_contact_struct():
+    """`rr_pipeline_init` at the state of [NB mjcf.ipynb cell 20]'s `Contact` struct (= the reset state of tests/golden/env_step_reset.json,
+    see tests/test_known_answers.py::test_contact_geometry_pinned_to_the_notebook_struct): the HIP kernel's contact distances, points and
+    frames of the 40 plane-capsule contacts against the reference's stored collision output, through the C ABI's contact outputs."""
+    from rodent_amd import assets, hip, mjcf
+    from tests.test_known_answers import check_contact_geometry_against_the_notebook
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    qpos = np.asarray(json.load(open(os.path.join(G, "env_step_reset.json")))["reset_qpos"])
+    golden = json.load(open(os.path.join(G, "mjcf_contact_struct.json")))
+    tab = mjcf.load_blob(assets.asset_path("rodent_optimized"))
+    batch = hip.Batch(hip.Model(assets.asset_path("rodent_optimized"), 8, 8), 2, torch.device(DEV))
+    st = batch.zeros_state()
+    st["qpos"][:] = torch.tensor(qpos, dtype=torch.float32, device=DEV)
+    nc = batch.dims.ncon
+    out = dict(contact_dist=torch.zeros(2, nc, device=DEV), contact_pos=torch.zeros(2, 3 * nc, device=DEV), contact_frame=torch.zeros(2, 9 * nc, device=DEV))
+    batch.pipeline_init(st, out)
+    torch.cuda.synchronize()
+    got = check_contact_geometry_against_the_notebook(out["contact_dist"][0].cpu().numpy().astype(np.float64),
+                                                      out["contact_pos"][0].cpu().numpy().astype(np.float64).reshape(-1, 3),
+                                                      out["contact_frame"][0].cpu().numpy().astype(np.float64).reshape(-1, 3, 3), golden, tab, tol=5e-7, ftol=1e-6)
+    print("HIP vs notebook Contact: max |ddist| %.1e, |dpos| %.1e, |dframe| %.1e" % got)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    open(os.path.join(out_dir, "reference_pin_contacts_hip.txt"), "w").write("HIP rr_pipeline_init vs [NB mjcf.ipynb cell 20] Contact, 40 plane-capsule contacts: max |ddist| %.2e m, |dpos| %.2e m, |dframe| %.2e\n" % got)

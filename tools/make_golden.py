@@ -57,6 +57,7 @@ def main():
     golden = {"source": "mjcf.ipynb stored outputs (cells 7 and 20), model rodent_optimized.xml of 2024-03",
               "link_names": names,
               "contact_dist": arr("dist", "pos="),
+              "contact_pos": arr("pos", "frame="),
               "contact_frame": arr("frame", "includemargin="),
               "contact_friction": arr("friction", "solref="),
               "contact_solref": arr("solref", "solreffriction="),
