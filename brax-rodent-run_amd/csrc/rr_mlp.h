@@ -35,6 +35,7 @@ struct RRMlpNet {
 };
 struct RRMlpArgs {
   const float* obs; int M, K;
+  int ld0;                                   // row stride (floats) of the FIRST-layer weight matrices: K, or K rounded up to a multiple of 4 (16-byte aligned rows)
   const int64_t* rows;                       // nullable: sample m reads row rows[m] of `obs` (a minibatch addressed in place)
   const float* mean; const float* std_;      // nullable: no normalisation
   RRMlpNet pol, val;                         // nlayers == 0: that network is skipped
@@ -247,8 +248,8 @@ __global__ __launch_bounds__(256, RR_MLP_FWD_WGS) void rr_mlp_forward_kernel(con
           }
         }
       }
-      if (has_val) S.gv.template fetch<FULL>(A.val.W[0], K, 0, RR_MLP_VH, k0, K);
-      if (has_pol) S.gp.template fetch<FULL>(A.pol.W[0], K, 0, RR_MLP_PH, k0, K);
+      if (has_val) S.gv.template fetch<FULL>(A.val.W[0], A.ld0, 0, RR_MLP_VH, k0, K);
+      if (has_pol) S.gp.template fetch<FULL>(A.pol.W[0], A.ld0, 0, RR_MLP_PH, k0, K);
     };
     auto fetch = [&](Stage& S, int c) {            // uniform branch: only the last chunk can be partial
       if ((c + 1) * RR_MLP_KC <= K) fetch_t(S, c, std::true_type{});
