@@ -588,7 +588,10 @@ def compile_mjcf(xml_path: str, *, iterations: int = 6, ls_iterations: int = 6,
         m.update(build_kernel_tables(m))
         # two identical trees (rodent_pair.xml): the kernel tables of ONE replica as `h_*` (h_k_dof_i, ...) + its dims `h_dims`; the
         # library then steps such a model with one wavefront per replica (csrc/rr_kernel.h, PAIR instances)
-        half = replica_model(m)
+        try:
+            half = replica_model(m)
+        except ValueError:                 # two trees that are not identical replicas: the generic one-wave instance steps the model
+            half = None
         if half is not None:
             hk = build_kernel_tables(half)
             m.update({"h_" + k: v for k, v in hk.items()})
