@@ -852,6 +852,9 @@ extern "C" int rr_mlp_value_backward(const float* grad_value, const float* head_
 }
 
 // weight gradient dW = delta' h as a split-row matrix-core product (csrc/rr_mlp.h)
+#ifndef RR_DW_KC128
+#define RR_DW_KC128 16      // rows of a staged chunk of the 128 x 128-tile weight-gradient kernel (32: half the LDS hand-offs, twice the bytes in flight)
+#endif
 struct DwPlan { int to, ti, kc, rows_per_slice, nslice; };
 // `group_tiles`: output tiles of ALL products that share this product's launch (rr_mlp_weight_grad_batch runs the products of one tile
 // shape as one launch, item = grid z); 0 = the product is launched alone.  The slices are cut so that the LAUNCH has ~target workgroups:
@@ -861,7 +864,7 @@ static DwPlan dw_plan(int M, int O, int I, int group_tiles = 0) {
   DwPlan p;
   p.to = O <= 32 ? 32 : (O <= 64 ? 64 : 128);
   p.ti = O <= 32 ? 128 : (O <= 64 ? 64 : 128);
-  p.kc = O <= 32 ? 64 : (O <= 64 ? 32 : 16);             // equal matrix-core work per LDS hand-off in the three tile shapes
+  p.kc = O <= 32 ? 64 : (O <= 64 ? 32 : RR_DW_KC128);    // equal matrix-core work per LDS hand-off in the three tile shapes
   const int tiles = group_tiles > 0 ? group_tiles : ((O + p.to - 1) / p.to) * ((I + p.ti - 1) / p.ti);
   static const int target = [] { const char* e = getenv("RR_DW_TARGET_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();   // workgroups per product
   static const int target_batch = [] { const char* e = getenv("RR_DW_TARGET_WGS_BATCH"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();   // ... per batched launch: two resident rounds
@@ -946,7 +949,7 @@ extern "C" int rr_mlp_weight_grad_batch(const rr_dw_item* items, int32_t n, void
   }
   hipStream_t st = (hipStream_t)stream;
   int rc = RR_OK;
-  if (grp[2].n) rc = dw_launch<2, 2, 2, 2, 16>(grp[2], ggrid[2], st);      // the big tiles first: they are the long ones
+  if (grp[2].n) rc = dw_launch<2, 2, 2, 2, RR_DW_KC128>(grp[2], ggrid[2], st);      // the big tiles first: they are the long ones
   if (!rc && grp[1].n) rc = dw_launch<2, 2, 1, 1, 32>(grp[1], ggrid[1], st);
   if (!rc && grp[0].n) rc = dw_launch<1, 4, 1, 1, 64>(grp[0], ggrid[0], st);
   if (rc) return rc;
