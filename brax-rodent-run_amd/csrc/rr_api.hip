@@ -6,6 +6,7 @@
 #include "rr_ppo.h"
 
 #include <atomic>
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -772,6 +773,20 @@ extern "C" int rr_mlp_forward_ld(const float* obs, const int64_t* obs_rows, int3
   if ((rc = mlp_net(policy, K, RR_MLP_PH, false, &A.pol, "policy")) || (rc = mlp_net(value, K, RR_MLP_VH, true, &A.val, "value"))) return rc;
   A.obs = obs; A.rows = obs_rows; A.M = M; A.K = K; A.ld0 = ld0; A.mean = mean; A.std_ = std_;
   A.pol_out = policy_out; A.val_out = value_out; A.pol_act = policy ? policy_pre : nullptr; A.val_act = value ? value_pre : nullptr;
+  // large batches (the learner's minibatch): three row tiles per workgroup sharing one weight stage (rr_mlp_forward3_kernel); small ones (a
+  // rollout step) keep one 32-row tile per workgroup -- more workgroups than CUs matter more there.  RR_MLP_FWD3=0 forces the latter.
+  static const int fwd3_min_rows = [] { const char* e = getenv("RR_MLP_FWD3"); return e && e[0] == '0' ? INT32_MAX : 8192; }();
+  if (M >= fwd3_min_rows) {
+    const size_t lds3 = RR_FWD3_LDS_FLOATS * sizeof(float);
+    static bool attr3_set = false;
+    if (!attr3_set) {
+      HIPCHK(hipFuncSetAttribute((const void*)rr_mlp_forward3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+      attr3_set = true;
+    }
+    hipLaunchKernelGGL(rr_mlp_forward3_kernel, dim3((M + RR_FWD3_BM - 1) / RR_FWD3_BM), dim3(RR_FWD3_NT), lds3, (hipStream_t)stream, A);
+    HIPCHK(hipGetLastError());
+    return RR_OK;
+  }
   const size_t lds = RR_MLP_LDS_FLOATS * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
