@@ -756,37 +756,17 @@ static int mlp_net(const rr_mlp_net* n, int K, int hidden, bool is_value, RRMlpN
   return RR_OK;
 }
 
-extern "C" int rr_mlp_forward_ld(const float* obs, const int64_t* obs_rows, int32_t M, int32_t K, const float* mean, const float* std_, const rr_mlp_net* policy,
-                                 const rr_mlp_net* value, float* policy_out, float* value_out, float* policy_pre, float* value_pre, int32_t ld0, void* stream);
 extern "C" int rr_mlp_forward(const float* obs, const int64_t* obs_rows, int32_t M, int32_t K, const float* mean, const float* std_, const rr_mlp_net* policy,
                               const rr_mlp_net* value, float* policy_out, float* value_out, float* policy_pre, float* value_pre, void* stream) {
-  return rr_mlp_forward_ld(obs, obs_rows, M, K, mean, std_, policy, value, policy_out, value_out, policy_pre, value_pre, K, stream);
-}
-extern "C" int rr_mlp_forward_ld(const float* obs, const int64_t* obs_rows, int32_t M, int32_t K, const float* mean, const float* std_, const rr_mlp_net* policy,
-                                 const rr_mlp_net* value, float* policy_out, float* value_out, float* policy_pre, float* value_pre, int32_t ld0, void* stream) {
-  if (!obs || M <= 0 || K <= 0 || (!policy && !value) || ld0 < K) return fail(RR_EINVAL, "rr_mlp_forward: bad argument");
+  if (!obs || M <= 0 || K <= 0 || (!policy && !value)) return fail(RR_EINVAL, "rr_mlp_forward: bad argument");
   if ((mean == nullptr) != (std_ == nullptr)) return fail(RR_EINVAL, "rr_mlp_forward: mean and std must be given together");
   if ((policy && !policy_out) || (value && !value_out)) return fail(RR_EINVAL, "rr_mlp_forward: missing output buffer");
   RRMlpArgs A;
   memset(&A, 0, sizeof(A));
   int rc;
   if ((rc = mlp_net(policy, K, RR_MLP_PH, false, &A.pol, "policy")) || (rc = mlp_net(value, K, RR_MLP_VH, true, &A.val, "value"))) return rc;
-  A.obs = obs; A.rows = obs_rows; A.M = M; A.K = K; A.ld0 = ld0; A.mean = mean; A.std_ = std_;
+  A.obs = obs; A.rows = obs_rows; A.M = M; A.K = K; A.mean = mean; A.std_ = std_;
   A.pol_out = policy_out; A.val_out = value_out; A.pol_act = policy ? policy_pre : nullptr; A.val_act = value ? value_pre : nullptr;
-  // large batches (the learner's minibatch): three row tiles per workgroup sharing one weight stage (rr_mlp_forward3_kernel); small ones (a
-  // rollout step) keep one 32-row tile per workgroup -- more workgroups than CUs matter more there.  RR_MLP_FWD3=0 forces the latter.
-  static const int fwd3_min_rows = [] { const char* e = getenv("RR_MLP_FWD3"); return e && e[0] == '0' ? INT32_MAX : 8192; }();
-  if (M >= fwd3_min_rows) {
-    const size_t lds3 = RR_FWD3_LDS_FLOATS * sizeof(float);
-    static bool attr3_set = false;
-    if (!attr3_set) {
-      HIPCHK(hipFuncSetAttribute((const void*)rr_mlp_forward3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-      attr3_set = true;
-    }
-    hipLaunchKernelGGL(rr_mlp_forward3_kernel, dim3((M + RR_FWD3_BM - 1) / RR_FWD3_BM), dim3(RR_FWD3_NT), lds3, (hipStream_t)stream, A);
-    HIPCHK(hipGetLastError());
-    return RR_OK;
-  }
   const size_t lds = RR_MLP_LDS_FLOATS * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {

@@ -35,7 +35,6 @@ struct RRMlpNet {
 };
 struct RRMlpArgs {
   const float* obs; int M, K;
-  int ld0;                                   // row stride (floats) of the FIRST-layer weight matrices: K, or K rounded up to a multiple of 4 (16-byte aligned rows)
   const int64_t* rows;                       // nullable: sample m reads row rows[m] of `obs` (a minibatch addressed in place)
   const float* mean; const float* std_;      // nullable: no normalisation
   RRMlpNet pol, val;                         // nlayers == 0: that network is skipped
@@ -248,8 +247,8 @@ __global__ __launch_bounds__(256, RR_MLP_FWD_WGS) void rr_mlp_forward_kernel(con
           }
         }
       }
-      if (has_val) S.gv.template fetch<FULL>(A.val.W[0], A.ld0, 0, RR_MLP_VH, k0, K);
-      if (has_pol) S.gp.template fetch<FULL>(A.pol.W[0], A.ld0, 0, RR_MLP_PH, k0, K);
+      if (has_val) S.gv.template fetch<FULL>(A.val.W[0], K, 0, RR_MLP_VH, k0, K);
+      if (has_pol) S.gp.template fetch<FULL>(A.pol.W[0], K, 0, RR_MLP_PH, k0, K);
     };
     auto fetch = [&](Stage& S, int c) {            // uniform branch: only the last chunk can be partial
       if ((c + 1) * RR_MLP_KC <= K) fetch_t(S, c, std::true_type{});
@@ -359,224 +358,6 @@ __global__ __launch_bounds__(256, RR_MLP_FWD_WGS) void rr_mlp_forward_kernel(con
     for (int k = part; k < RR_MLP_VH; k += 8) s = fmaf(actV[m * RR_SV + k], w[k], s);
     s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
     if (part == 0 && row0 + m < M) A.val_out[row0 + m] = s + A.val.b[l][0];
-  }
-}
-
-// ------------------------------------------------------------------------------------------ forward, three row tiles per workgroup
-// rr_mlp_forward_kernel re-stages every weight chunk once per 32 rows: three co-resident workgroups of a CU each pull the same 20 KB per
-// chunk through L2, and each of them waits out the latency of its loads between two barriers (the matrix pipes of that kernel are busy
-// 35-40 % of the time; shortening its vector stream, deepening its prefetch at two workgroups per CU or aligning its loads changed nothing,
-// DESIGN.md section 4b).  This kernel is those three workgroups merged: 768 threads = 3 row tiles x 4 column groups, 96 rows, ONE weight
-// stage per chunk shared by the three row tiles.  A thread then carries only two 16-byte pieces of a weight chunk, so THREE register stages
-// fit (the loads of chunk c + 3 are issued while chunk c is multiplied: two chunk periods to land instead of one), and the LDS stage is
-// double buffered: chunk c + 1 is written while chunk c is read, one barrier per chunk instead of two.  Same arithmetic, same k order, same
-// epilogues as rr_mlp_forward_kernel (the helpers are shared): results are bit-identical to it.
-#define RR_FWD3_RT 3
-#define RR_FWD3_NT (256 * RR_FWD3_RT)
-constexpr int RR_FWD3_BM = 32 * RR_FWD3_RT;
-constexpr int RR_FWD3_LDS_A = RR_FWD3_RT * RR_MLP_BM * RR_SV;                     // activations; during layer 1: 2 x (x tiles + weight chunk)
-constexpr int RR_FWD3_LDS_B = 2 * RR_MLP_VH * RR_SX;                              // two hidden-layer weight chunks; before them: policy weights + activations
-constexpr int RR_FWD3_ACTP_AT = 2 * 64 * RR_SX;
-constexpr int RR_FWD3_LDS_FLOATS = RR_FWD3_LDS_A + RR_FWD3_LDS_B;
-static_assert(2 * (RR_FWD3_RT * RR_MLP_BM * RR_SX + (RR_MLP_VH + RR_MLP_PH) * RR_SX) <= RR_FWD3_LDS_A, "both layer-1 stages fit the activation region");
-static_assert(RR_FWD3_ACTP_AT + RR_FWD3_RT * RR_MLP_BM * RR_SP <= RR_FWD3_LDS_B, "policy weights and activations fit region B");
-
-// a [256 rows][16] weight chunk moved by 768 threads: 1024 16-byte pieces, thread t takes piece t and (t < 256) piece t + 768
-struct RRStageW3 {
-  rr_f4 r[2];
-  template <bool FULL>
-  __device__ __forceinline__ void fetch(const float* src, int ld, int k0, int K) {
-    const int t = threadIdx.x;
-    r[0] = RRStage<RR_MLP_VH>::load4<FULL>(src + (size_t)(t >> 2) * ld, k0 + 4 * (t & 3), K);
-    const int v = min(t + RR_FWD3_NT, RR_MLP_VH * 4 - 1);
-    r[1] = RRStage<RR_MLP_VH>::load4<FULL>(src + (size_t)(v >> 2) * ld, k0 + 4 * (v & 3), K);
-  }
-  __device__ __forceinline__ void commit(float* dst) const {
-    const int t = threadIdx.x;
-    float* d = dst + (t >> 2) * RR_SX + 4 * (t & 3);
-    *(rr_f2v*)d = rr_f2v{r[0][0], r[0][1]};
-    *(rr_f2v*)(d + 2) = rr_f2v{r[0][2], r[0][3]};
-    if (t < RR_MLP_VH * 4 - RR_FWD3_NT) {
-      const int v = t + RR_FWD3_NT;
-      float* e = dst + (v >> 2) * RR_SX + 4 * (v & 3);
-      *(rr_f2v*)e = rr_f2v{r[1][0], r[1][1]};
-      *(rr_f2v*)(e + 2) = rr_f2v{r[1][2], r[1][3]};
-    }
-  }
-};
-
-__global__ __launch_bounds__(RR_FWD3_NT, 3) void rr_mlp_forward3_kernel(const RRMlpArgs A) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wv = wave & 3, wr = wave >> 2, tl = threadIdx.x & 255;
-  float* actV = lds + wr * RR_MLP_BM * RR_SV;                       // this row tile's value activations
-  float* sB = lds + RR_FWD3_LDS_A;
-  float* actP = sB + RR_FWD3_ACTP_AT + wr * RR_MLP_BM * RR_SP;
-  const int row0 = blockIdx.x * RR_FWD3_BM + RR_MLP_BM * wr;       // first row of this row tile
-  const bool has_val = A.val.nlayers > 0, has_pol = A.pol.nlayers > 0;
-  const int M = A.M, K = A.K;
-  constexpr int XS = RR_FWD3_RT * RR_MLP_BM * RR_SX, WS = (RR_MLP_VH + RR_MLP_PH) * RR_SX;       // floats of the x tiles / of a weight chunk
-  auto bufX = [&](int b) { return lds + b * (XS + WS) + wr * RR_MLP_BM * RR_SX; };
-  auto bufW = [&](int b) { return lds + b * (XS + WS) + XS; };
-
-  // ------------------------------------------------------------------ layer 1 of both nets
-  {
-    rr_f16 a0 = {0}, a1 = {0};
-    rr_f4 ap = {0, 0, 0, 0};
-    // the small tiles move in 8-byte pieces so that a register stage stays small (three of them are alive): the [32][16] observation tile of a
-    // row tile = 256 pieces, one per thread of the row tile (row tl / 8); the [32][16] policy weight chunk = 256 pieces, threads 0..255
-    struct Stage { RRStageW3 gv; rr_f2v gp, gx, mu, sd; };
-    Stage S0, S1, S2;
-    const int nchunk = (K + RR_MLP_KC - 1) / RR_MLP_KC;
-    const int xm = min(row0 + (tl >> 3), M - 1);
-    const long long xoff = (long long)(A.rows ? A.rows[xm] : xm) * K;
-    const int pn = min((int)threadIdx.x, 255) >> 3;
-    auto load2 = [&](const float* row, int k, auto full) {
-      constexpr bool FULL = decltype(full)::value;
-      typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-      if (FULL) { const f2u u = *(const f2u*)(row + k); return rr_f2v{u[0], u[1]}; }
-      rr_f2v t;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) { const float x = row[min(k + j, K - 1)]; t[j] = k + j < K ? x : 0.0f; }
-      return t;
-    };
-    auto fetch_t = [&](Stage& S, int c, auto full) {
-      constexpr bool FULL = decltype(full)::value;
-      const int k0 = c * RR_MLP_KC, kx = k0 + 2 * (tl & 7);
-      S.gx = load2(A.obs + xoff, kx, full);
-      if (A.mean) {
-        S.mu = load2(A.mean, kx, full);
-        S.sd = load2(A.std_, kx, full);
-        if (!FULL) {
-#pragma unroll
-          for (int j = 0; j < 2; ++j) S.sd[j] = kx + j < K ? S.sd[j] : 1.0f;
-        }
-      }
-      if (has_val) S.gv.fetch<FULL>(A.val.W[0], A.ld0, k0, K);
-      if (has_pol) S.gp = load2(A.pol.W[0] + (size_t)pn * A.ld0, k0 + 2 * (threadIdx.x & 7), full);
-    };
-    auto fetch = [&](Stage& S, int c) {
-      if ((c + 1) * RR_MLP_KC <= K) fetch_t(S, c, std::true_type{});
-      else fetch_t(S, c, std::false_type{});
-    };
-    auto commit = [&](Stage& S, int b) {
-      {
-        rr_f2v x = S.gx;
-        if (A.mean) {
-#pragma unroll
-          for (int j = 0; j < 2; ++j) x[j] = (x[j] - S.mu[j]) / S.sd[j];
-        }
-        *(rr_f2v*)(bufX(b) + (tl >> 3) * RR_SX + 2 * (tl & 7)) = x;
-      }
-      if (has_val) S.gv.commit(bufW(b));
-      if (has_pol && threadIdx.x < 256) *(rr_f2v*)(bufW(b) + (RR_MLP_VH + (threadIdx.x >> 3)) * RR_SX + 2 * (threadIdx.x & 7)) = S.gp;
-    };
-    auto compute = [&](int b) {
-      if (has_val && has_pol) rr_mlp_chunk<true, true>(bufX(b), RR_SX, 0, bufW(b), RR_MLP_VH, a0, a1, ap, lane, wv);
-      else if (has_val) rr_mlp_chunk<true, false>(bufX(b), RR_SX, 0, bufW(b), RR_MLP_VH, a0, a1, ap, lane, wv);
-      else rr_mlp_chunk<false, true>(bufX(b), RR_SX, 0, bufW(b), RR_MLP_VH, a0, a1, ap, lane, wv);
-    };
-    // Chunk c lives in LDS buffer c & 1.  Iteration c: barrier (buffer c & 1 is complete; every wave has finished multiplying chunk c - 1, so
-    // buffer (c + 1) & 1 is free) -> write chunk c + 1 from its register stage into the other buffer -> request chunk c + 4 into that stage
-    // -> multiply chunk c.  A chunk's loads thus have three chunk periods to land; the write of chunk c + 1 overlaps the multiplication of
-    // chunk c in every wave's own instruction stream.
-    fetch(S0, 0);
-    if (nchunk > 1) fetch(S1, 1);
-    if (nchunk > 2) fetch(S2, 2);
-    commit(S0, 0);
-    if (nchunk > 3) fetch(S0, 3);
-    auto iter = [&](Stage& Snext, int c) {          // Snext holds chunk c + 1
-      __syncthreads();
-      if (c + 1 < nchunk) { commit(Snext, (c + 1) & 1); if (c + 4 < nchunk) fetch(Snext, c + 4); }
-      compute(c & 1);
-    };
-    for (int c = 0; c < nchunk; c += 3) {
-      iter(S1, c);
-      if (c + 1 < nchunk) iter(S2, c + 1);
-      if (c + 2 < nchunk) iter(S0, c + 2);
-    }
-    __syncthreads();            // every wave is done with the stages before the activations overwrite them
-    if (has_val) rr_mlp_store_val(actV, a0, a1, A.val.b[0], lane, wv, A.val_act, row0, M);
-    if (has_pol) rr_mlp_store_pol(actP, ap, A.pol.b[0], lane, wv, A.pol_act, row0, M);
-    __syncthreads();
-  }
-
-  // ------------------------------------------------------------------ policy hidden layers and head (region B; per row tile, as rr_mlp_forward_kernel)
-  for (int l = 1; has_pol && l < A.pol.nlayers; ++l) {
-    const bool head = l == A.pol.nlayers - 1;
-    const int nout = head ? A.pol.out_dim : RR_MLP_PH;
-    __syncthreads();
-    for (int e = threadIdx.x; e < 64 * RR_MLP_PH; e += RR_FWD3_NT) {
-      const int n = e / RR_MLP_PH, k = e % RR_MLP_PH;
-      sB[(64 * (k / RR_MLP_KC) + n) * RR_SX + (k % RR_MLP_KC)] = n < nout ? A.pol.W[l][n * RR_MLP_PH + k] : 0.0f;
-    }
-    __syncthreads();
-    if (!head) {
-      rr_f16 d0 = {0}, d1 = {0};
-      rr_f4 ap = {0, 0, 0, 0};
-      rr_mlp_chunk<false, true>(actP, RR_SP, 0, sB, 0, d0, d1, ap, lane, wv);
-      rr_mlp_chunk<false, true>(actP, RR_SP, RR_MLP_KC, sB, 64, d0, d1, ap, lane, wv);
-      __syncthreads();
-      rr_mlp_store_pol(actP, ap, A.pol.b[l], lane, wv, A.pol_act ? A.pol_act + (size_t)l * M * RR_MLP_PH : nullptr, row0, M);
-    } else {
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        rr_f4 ap = {0, 0, 0, 0};
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const float* xr = actP + (16 * mt + (lane & 15)) * RR_SP + c * RR_MLP_KC + (lane >> 4);
-          const float* w0 = sB + (64 * c + 16 * wv + (lane & 15)) * RR_SX + (lane >> 4);
-#pragma unroll
-          for (int kk = 0; kk < RR_MLP_KC; kk += 4) ap = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[kk], w0[kk], ap, 0, 0, 0);
-        }
-        const int n = 16 * wv + (lane & 15);
-        if (n < nout) {
-          const float bn = A.pol.b[l][n];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int m = 16 * mt + 4 * (lane >> 4) + r;
-            if (row0 + m < M) A.pol_out[(size_t)(row0 + m) * nout + n] = ap[r] + bn;
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();        // the policy is done with region B
-  // ------------------------------------------------------------------ value hidden layers: weight chunks [256][16] through three register stages and two LDS buffers
-  for (int l = 1; has_val && l < A.val.nlayers - 1; ++l) {
-    rr_f16 a0 = {0}, a1 = {0};
-    rr_f4 ap = {0, 0, 0, 0};
-    constexpr int nchunk = RR_MLP_VH / RR_MLP_KC;
-    const float* W = A.val.W[l];
-    RRStageW3 G0, G1, G2;
-    G0.fetch<true>(W, RR_MLP_VH, 0, RR_MLP_VH);
-    G1.fetch<true>(W, RR_MLP_VH, RR_MLP_KC, RR_MLP_VH);
-    G2.fetch<true>(W, RR_MLP_VH, 2 * RR_MLP_KC, RR_MLP_VH);
-    G0.commit(sB);
-    G0.fetch<true>(W, RR_MLP_VH, 3 * RR_MLP_KC, RR_MLP_VH);
-    auto iter = [&](RRStageW3& Gn, int c) {        // Gn holds chunk c + 1
-      __syncthreads();
-      if (c + 1 < nchunk) { Gn.commit(sB + ((c + 1) & 1) * RR_MLP_VH * RR_SX); if (c + 4 < nchunk) Gn.fetch<true>(W, RR_MLP_VH, (c + 4) * RR_MLP_KC, RR_MLP_VH); }
-      rr_mlp_chunk<true, false>(actV, RR_SV, c * RR_MLP_KC, sB + (c & 1) * RR_MLP_VH * RR_SX, 0, a0, a1, ap, lane, wv);
-    };
-#pragma unroll 1
-    for (int c = 0; c < nchunk; c += 3) {
-      iter(G1, c);
-      if (c + 1 < nchunk) iter(G2, c + 1);
-      if (c + 2 < nchunk) iter(G0, c + 2);
-    }
-    __syncthreads();        // every wave has read the whole input tile and the last weight chunk
-    rr_mlp_store_val(actV, a0, a1, A.val.b[l], lane, wv, A.val_act ? A.val_act + (size_t)l * M * RR_MLP_VH : nullptr, row0, M);
-    __syncthreads();
-  }
-  if (has_val) {            // value head 256 -> 1: eight lanes per row
-    const int l = A.val.nlayers - 1;
-    const int m = tl >> 3, part = tl & 7;
-    const float* w = A.val.W[l];
-    float sacc = 0.0f;
-#pragma unroll 8
-    for (int k = part; k < RR_MLP_VH; k += 8) sacc = fmaf(actV[m * RR_SV + k], w[k], sacc);
-    sacc += __shfl_xor(sacc, 1); sacc += __shfl_xor(sacc, 2); sacc += __shfl_xor(sacc, 4);
-    if (part == 0 && row0 + m < M) A.val_out[row0 + m] = sacc + A.val.b[l][0];
   }
 }
 

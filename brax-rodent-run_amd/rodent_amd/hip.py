@@ -65,7 +65,7 @@ class RRPpoCfg(C.Structure):
 
 EXPORTS = ["rr_model_load", "rr_model_dims", "rr_model_set_solver", "rr_model_set_solver_type", "rr_model_destroy", "rr_model_table", "rr_kernarg_layout", "rr_batch_create",
            "rr_batch_destroy", "rr_pipeline_init", "rr_pipeline_step", "rr_env_step", "rr_env_reset", "rr_pipeline_step_to", "rr_env_step_to", "rr_batch_contact_overflow", "rr_batch_unroll_supported", "rr_env_unroll", "rr_env_unroll_policy",
-           "rr_compute_gae", "rr_mlp_forward", "rr_mlp_forward_ld", "rr_ppo_loss_workspace_bytes", "rr_ppo_loss", "rr_policy_act_workspace_bytes", "rr_policy_act", "rr_policy_sample", "rr_policy_backward_workspace_bytes", "rr_policy_backward", "rr_mlp_silu_backward_workspace_bytes", "rr_mlp_silu_backward", "rr_mlp_value_backward_workspace_bytes", "rr_mlp_value_backward", "rr_mlp_weight_grad_workspace_bytes", "rr_mlp_weight_grad", "rr_mlp_weight_grad_batch_workspace_bytes", "rr_mlp_weight_grad_batch", "rr_obs_moments_workspace_bytes", "rr_obs_moments", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_schedule", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
+           "rr_compute_gae", "rr_mlp_forward", "rr_ppo_loss_workspace_bytes", "rr_ppo_loss", "rr_policy_act_workspace_bytes", "rr_policy_act", "rr_policy_sample", "rr_policy_backward_workspace_bytes", "rr_policy_backward", "rr_mlp_silu_backward_workspace_bytes", "rr_mlp_silu_backward", "rr_mlp_value_backward_workspace_bytes", "rr_mlp_value_backward", "rr_mlp_weight_grad_workspace_bytes", "rr_mlp_weight_grad", "rr_mlp_weight_grad_batch_workspace_bytes", "rr_mlp_weight_grad_batch", "rr_obs_moments_workspace_bytes", "rr_obs_moments", "rr_wrap_episode_autoreset", "rr_debug_layout", "rr_batch_set_schedule", "rr_batch_set_profile", "rr_batch_set_timing", "rr_batch_kernel_time", "rr_last_error"]
 
 _lib = None
 
@@ -108,8 +108,6 @@ def lib():
         L.rr_compute_gae.argtypes = [C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rr_mlp_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(RRMlpNet), C.POINTER(RRMlpNet),
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.rr_mlp_forward_ld.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(RRMlpNet), C.POINTER(RRMlpNet),
-                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         L.rr_ppo_loss_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
         L.rr_ppo_loss_workspace_bytes.restype = C.c_size_t
         L.rr_ppo_loss.argtypes = [C.c_void_p] * 9 + [C.c_int32] * 3 + [C.POINTER(RRPpoCfg)] + [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]
@@ -417,7 +415,7 @@ def _mlp_net(weights, biases, in_dim=None):
     return RRMlpNet(C.cast(W, C.POINTER(C.c_void_p)), C.cast(B, C.POINTER(C.c_void_p)), C.cast(S, C.POINTER(C.c_int32)), n), (W, B, S)
 
 
-def mlp_forward(obs, mean=None, std=None, policy=None, value=None, want_pre=False, rows=None, pad_first=None):
+def mlp_forward(obs, mean=None, std=None, policy=None, value=None, want_pre=False, rows=None):
     """Fused normalise + policy MLP + value MLP forward on the f32 matrix cores (C ABI `rr_mlp_forward`).
 
     obs [M, K] float32 device; policy / value: (weights, biases) lists in nn.Linear layout or None.  Returns
@@ -432,15 +430,6 @@ def mlp_forward(obs, mean=None, std=None, policy=None, value=None, want_pre=Fals
     pn = vn = None
     keep = []
     pol_out = val_out = pol_pre = val_pre = None
-    # first-layer weights with 16-byte aligned rows (K = 1263 is not a multiple of 4): a padded copy per call, the kernel told its row stride
-    ld0 = K
-    if pad_first is None:
-        pad_first = os.environ.get("RR_MLP_PAD", "0") == "1"      # measured: 0.455 ms padded (incl. the two pad copies) vs 0.448 ms -- no gain, off
-    if pad_first and K % 4:
-        ld0 = (K + 3) // 4 * 4
-        padw = lambda net: ([torch.nn.functional.pad(net[0][0], (0, ld0 - K))] + list(net[0][1:]), net[1])
-        policy = padw(policy) if policy is not None else None
-        value = padw(value) if value is not None else None
     if policy is not None:
         pn, k = _mlp_net(*policy, in_dim=K); keep.append((k, policy))
         pol_out = torch.empty(M, policy[0][-1].shape[0], device=dev)
@@ -453,9 +442,9 @@ def mlp_forward(obs, mean=None, std=None, policy=None, value=None, want_pre=Fals
             val_pre = torch.empty(len(value[0]) - 1, M, 256, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     p = lambda t: t.data_ptr() if t is not None else None
-    _check(lib().rr_mlp_forward_ld(obs.data_ptr(), rows.data_ptr() if rows is not None else None, M, K, _ptr(mean, numel=K) if mean is not None else None,
-                                   _ptr(std, numel=K) if std is not None else None, C.byref(pn) if pn is not None else None,
-                                   C.byref(vn) if vn is not None else None, p(pol_out), p(val_out), p(pol_pre), p(val_pre), ld0, C.c_void_p(stream)))
+    _check(lib().rr_mlp_forward(obs.data_ptr(), rows.data_ptr() if rows is not None else None, M, K, _ptr(mean, numel=K) if mean is not None else None,
+                                _ptr(std, numel=K) if std is not None else None, C.byref(pn) if pn is not None else None,
+                                C.byref(vn) if vn is not None else None, p(pol_out), p(val_out), p(pol_pre), p(val_pre), C.c_void_p(stream)))
     return pol_out, val_out, pol_pre, val_pre
 
 

@@ -211,11 +211,7 @@ typedef struct rr_mlp_net {
 } rr_mlp_net;
 int rr_mlp_forward(const float* obs, const int64_t* obs_rows, int32_t M, int32_t K, const float* mean, const float* std, const rr_mlp_net* policy,
                    const rr_mlp_net* value, float* policy_out, float* value_out, float* policy_pre, float* value_pre, void* stream);
-/* The same with the FIRST-layer weight matrices of both networks stored with row stride ld0 >= K floats (weights[0] is [sizes[1]][ld0]; columns
- * K.. are never read): with ld0 a multiple of 4 every 16-byte piece the kernel stages is 16-byte aligned -- an observation width like 1263 is not,
- * and the staging of the first layer is what the forward spends its L2 transactions on. */
-int rr_mlp_forward_ld(const float* obs, const int64_t* obs_rows, int32_t M, int32_t K, const float* mean, const float* std, const rr_mlp_net* policy,
-                      const rr_mlp_net* value, float* policy_out, float* value_out, float* policy_pre, float* value_pre, int32_t ld0, void* stream);
+
 
 /* The loss half of `brax.training.agents.ppo.losses.compute_ppo_loss` [UP; REF
  * brax_rodent_run_ppo.py:97-114] and its gradient with respect to the network outputs, in three launches without atomics
