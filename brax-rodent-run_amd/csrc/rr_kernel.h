@@ -483,7 +483,17 @@ struct Wave {
   // compiler keeps the program order of the LDS accesses around this point.
   // "memory" keeps the compiler from moving LDS accesses across; lgkmcnt(0) retires this wave's LDS operations
   // (incl. the float atomics) without draining outstanding global table prefetches (no vmcnt wait).
-  __device__ __forceinline__ void sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+#ifndef RR_SYNC_WAIT
+#define RR_SYNC_WAIT 1      // 0: compiler barrier only (experiment: the hardware's in-order LDS execution makes the wait redundant)
+#endif
+  __device__ __forceinline__ void sync() {
+#if RR_SYNC_WAIT
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+    asm volatile("" ::: "memory");
+#endif
+    __builtin_amdgcn_wave_barrier();
+  }
   __device__ __forceinline__ v3 get_com(int r) const {
     return mk3(r ? com1[0] : com0[0], r ? com1[1] : com0[1], r ? com1[2] : com0[2]);
   }
