@@ -57,13 +57,17 @@ static void layout(rr_model* m) {
   const int con_slots = m->dyn ? m->NCS * RR_LANES : d.ncon;      // DYN: the wave holds the pairs in penetration in its contact slots
   const RRLayout L = rr_layout(d.nq, d.nv, d.nu, d.nbody, d.nM, con_slots, m->solver == 2);
   k.o_H = L.o_H; k.o_Mp = L.o_Mp; k.o_anc = L.o_anc; k.solver = m->solver;
+  // factorisation schedule: with alias copies of the hot rows in the pose cells (levelsched.py); the Newton instances reuse the schedule
+  // on the Hessian's array through an address shift, which the alias cells would not follow, so they run the alias-free one
+  k.nfac = m->iscalar(m->solver == 2 ? "k_factor3p_rows" : "k_factor3_rows");
+  k.nalias = m->solver == 2 ? 0 : m->iscalar("k_nalias");
   m->dbg_names.clear(); m->dbg_off.clear(); m->dbg_size.clear(); m->dbg_cnames.clear();      // layout() may run again (rr_model_set_solver_type)
   k.o_qpos = L.o_qpos; k.o_qvel = L.o_qvel; k.o_act = L.o_act; k.o_ctrl = L.o_ctrl; k.o_xpos = L.o_xpos; k.o_xquat = L.o_xquat;
   k.o_cinert = L.o_cinert; k.o_cdof = L.o_cdof; k.o_cvel = L.o_cvel; k.o_qLD = L.o_qLD; k.o_vec = L.o_vec; k.o_x = L.o_x;
   k.o_arm = L.o_arm; k.o_warm = L.o_warm; k.o_qact = L.o_qact; k.o_jlist = L.o_jlist; k.lds_floats = L.lds_floats;
   const int o = L.lds_floats;
   // staging of the line search's compacted rows: cinert | cvel | pose regions each hold 4*ncon + nv floats
-  m->stage_ok = 2 * (d.nbody + 8) <= std::max(7 * d.nbody + 4, 6 * d.nv) && 6 * con_slots <= std::max(7 * d.nbody + 4, 6 * d.nv) && 4 * con_slots + d.nv <= std::min(std::min(10 * d.nbody, 6 * d.nbody), std::max(7 * d.nbody + 4, 6 * d.nv));
+  m->stage_ok = 2 * (k.nalias + 4) <= std::max(7 * d.nbody + 4, 6 * d.nv) && 2 * (d.nbody + 8) <= std::max(7 * d.nbody + 4, 6 * d.nv) && 6 * con_slots <= std::max(7 * d.nbody + 4, 6 * d.nv) && 4 * con_slots + d.nv <= std::min(std::min(10 * d.nbody, 6 * d.nbody), std::max(7 * d.nbody + 4, 6 * d.nv));
   if (m->dyn && d.nu > std::max(7 * d.nbody + 4, 6 * d.nv)) m->stage_ok = false;      // actuator forces go through the pose cells
   // debug dump
   int g = 0;
@@ -94,7 +98,7 @@ static void setup_replica(rr_model* m) {
   if (sw && sw[0] == '0') return;
   static const char* need[] = {"h_dims", "h_k_slots", "h_k_body_i", "h_k_body_f", "h_k_jnt_i", "h_k_jnt_f", "h_k_dof_i", "h_k_dof_f", "h_k_act_f", "h_k_M_ij_k",
                                "h_k_body_anc", "h_k_nround", "h_k_factor3", "h_k_factor3_rows", "h_k_linv", "h_k_linv_rows", "h_k_coljob", "h_k_rowjob", "h_k_jobown",
-                               "h_k_solve_lmax", "h_k_solve_cmax", "h_k_solve_rmax", "h_k_con_i", "h_k_con_f", "h_k_con_chain_rows", "h_k_root_mass"};
+                               "h_k_solve_lmax", "h_k_solve_cmax", "h_k_solve_rmax", "h_k_nalias", "h_k_con_i", "h_k_con_f", "h_k_con_chain_rows", "h_k_root_mass"};
   for (const char* n : need) if (!m->find(n)) return;
   const int32_t* hd = (const int32_t*)m->find("h_dims")->data;       // nq nv nu nbody njnt nM ncon dmax
   const int32_t* sl = (const int32_t*)m->find("h_k_slots")->data;
@@ -103,7 +107,7 @@ static void setup_replica(rr_model* m) {
   RRDims k = m->kd;          // options, gravity, tolerances, meaninertia: the model's
   k.nq = hd[0]; k.nv = hd[1]; k.nu = hd[2]; k.nbody = hd[3]; k.njnt = hd[4]; k.nM = hd[5]; k.ncon = hd[6]; k.dmax = hd[7];
   k.nroot = (int)m->find("h_k_root_mass")->count;
-  k.nround = m->iscalar("h_k_nround"); k.ninv = m->iscalar("h_k_linv_rows"); k.nfac = m->iscalar("h_k_factor3_rows");
+  k.nround = m->iscalar("h_k_nround"); k.ninv = m->iscalar("h_k_linv_rows"); k.nfac = m->iscalar("h_k_factor3_rows"); k.nalias = m->iscalar("h_k_nalias");
   k.lmax = m->iscalar("h_k_solve_lmax"); k.cmax = m->iscalar("h_k_solve_cmax"); k.rmax = m->iscalar("h_k_solve_rmax");
   k.obs_dim = k.nq + k.nv + 16 * (k.nbody - 1) + k.nv + 3;
   const RRLayout L = rr_layout(k.nq, k.nv, k.nu, k.nbody, k.nM, k.ncon, false);
@@ -119,7 +123,7 @@ static void setup_replica(rr_model* m) {
   if (k.nM > RR_LANES * 18 || k.nroot != 1) return;
   const bool stage_ok = 2 * (k.nbody + 8) <= std::max(7 * k.nbody + 4, 6 * k.nv) && 6 * k.ncon <= std::max(7 * k.nbody + 4, 6 * k.nv) &&
                         4 * k.ncon + k.nv <= std::min(std::min(10 * k.nbody, 6 * k.nbody), std::max(7 * k.nbody + 4, 6 * k.nv));
-  if (!stage_ok || 2 * k.lds_bytes_rep + 128 > 64 * 1024) return;
+  if (!stage_ok || 2 * (k.nalias + 4) > std::max(7 * k.nbody + 4, 6 * k.nv) || 2 * k.lds_bytes_rep + 128 > 64 * 1024) return;
   m->kd_rep = k;
   m->pair_ok = pick_pair_kernel(m) != nullptr;
 }
@@ -155,7 +159,7 @@ extern "C" int rr_model_load(const char* path, rr_model** out) {
   }
   static const char* need[] = {"nq", "nv", "nu", "nbody", "njnt", "ngeom", "nM", "ncon", "nlimit", "nefc", "obs_dim", "k_slots",
                                "k_body_i", "k_body_f", "k_jnt_i", "k_jnt_f", "k_dof_i", "k_dof_f", "k_act_f", "k_M_ij_k", "k_body_anc",
-                               "k_nround", "k_factor3", "k_factor3_rows", "k_linv", "k_linv_rows", "k_coljob", "k_rowjob",
+                               "k_nround", "k_factor3", "k_factor3_rows", "k_factor3p", "k_factor3p_rows", "k_nalias", "k_linv", "k_linv_rows", "k_coljob", "k_rowjob",
                                "k_jobown", "k_solve_lmax", "k_solve_cmax", "k_solve_rmax", "k_con_i", "k_con_f", "k_con_chain_packed", "k_con_chain_rows", "k_root_mass",
                                "k_act_i", "k_act_m_i", "k_act_m_f",
                                "dof_depth", "body_depth", "opt_timestep", "opt_gravity", "stat_meaninertia"};
@@ -183,7 +187,6 @@ extern "C" int rr_model_load(const char* path, rr_model** out) {
   k.nround = m->iscalar("k_nround");
   k.ninv = m->iscalar("k_linv_rows");
   if (d.nM > RR_LANES * (m->NVS == 1 ? 10 : (m->NVS == 2 ? 18 : 35))) { delete m; return fail(RR_EUNSUPPORTED, "rr_model_load: more mass-matrix entries than the kernel's register table"); }
-  k.nfac = m->iscalar("k_factor3_rows");
   { const int njs = (m->NVS >= 3 ? m->NVS + 1 : m->NVS) * RR_LANES;     // Wave::NJS job slots
     k.lmax = m->iscalar("k_solve_lmax"); k.cmax = m->iscalar("k_solve_cmax"); k.rmax = m->iscalar("k_solve_rmax");
     if ((int)m->find("k_coljob")->count != 9 * njs || (int)m->find("k_rowjob")->count != 5 * njs || k.lmax > 16 || k.lmax < 1 || k.cmax > 8 || k.rmax > 8 || k.cmax < 1) {
@@ -278,22 +281,26 @@ static int upload(rr_batch* b, const char* name, Ptr* dst) {
   return RR_OK;
 }
 
-// Level schedules (k_factor3, k_linv): element indices -> LDS byte addresses of the sparse-matrix array (rr_kernel.h run_levels).
+// Row schedules (k_factor3, k_linv): element indices -> LDS byte addresses (rr_kernel.h run_levels).  Indices below nM + 4 are cells of
+// the sparse-matrix array at `base`; the alias cells nM + 4 .. live at `alias_base` (the pose cells).
 // `copies` = 2 (two-wave instance): a second copy behind the first, addressed into the second wavefront's LDS region (+ rep_bytes).
-static int upload_levels(rr_batch* b, const char* name, rr_gi* dst, uint32_t base = ~0u, int copies = 1, uint32_t rep_bytes = 0) {
+static int upload_levels(rr_batch* b, const char* name, rr_gi* dst, uint32_t base, uint32_t alias_base, uint32_t nM, int copies = 1, uint32_t rep_bytes = 0) {
   const Entry* e = b->m->find(name);
-  if (base == ~0u) base = (uint32_t)b->m->kd.o_qLD * 4u;
   std::vector<uint32_t> t((size_t)copies * e->count);
   for (int c = 0; c < copies; ++c) {
     const uint32_t* src = (const uint32_t*)e->data;
     uint32_t* tc = t.data() + (size_t)c * e->count;
-    const uint32_t cb = base + (uint32_t)c * rep_bytes;
-    for (size_t i = 0; i + 3 < e->count; i += 4) {        // x = a | b0 << 16, y = d0 | d1 << 16, z = d2 | d3 << 16, w = q | flags << 8
+    const uint32_t cb = base + (uint32_t)c * rep_bytes, ab = alias_base + (uint32_t)c * rep_bytes;
+    for (size_t i = 0; i + 3 < e->count; i += 4) {        // x = a | b0 << 16, y = d0 | d1 << 16, z = d2 | d3 << 16, w = q
       uint32_t f[6] = {src[i] & 0xFFFFu, src[i] >> 16, src[i + 1] & 0xFFFFu, src[i + 1] >> 16, src[i + 2] & 0xFFFFu, src[i + 2] >> 16};
-      for (uint32_t& v : f) { v = v * 8u + cb; if (v > 0xFFFFu) return fail(RR_EUNSUPPORTED, "level schedule does not fit the 16-bit LDS address fields"); }   // 8 bytes per entry: pairs
-      const uint32_t q = (src[i + 3] & 0xFFu) * 8u, flags = src[i + 3] >> 8;
+      for (uint32_t& v : f) {                              // 8 bytes per entry: pairs
+        v = v < nM + 4u ? v * 8u + cb : (v - (nM + 4u)) * 8u + ab;
+        if (v > 0xFFFFu) return fail(RR_EUNSUPPORTED, "level schedule does not fit the 16-bit LDS address fields");
+      }
+      const uint32_t q = src[i + 3];
+      if (q > 255u) return fail(RR_EIO, "level schedule: pivot offset out of range (stale blob)");
       tc[i] = f[0] | (f[1] << 16); tc[i + 1] = f[2] | (f[3] << 16); tc[i + 2] = f[4] | (f[5] << 16);
-      tc[i + 3] = q | (flags << 16);
+      tc[i + 3] = q * 8u;
     }
   }
   void* p = nullptr;
@@ -354,7 +361,10 @@ extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t devi
   UP(act_f, "k_act_f") UP(con_f, "k_con_f") UP(root_mass, "k_root_mass")
   UP(act_i, "k_act_i") UP(act_m_i, "k_act_m_i") UP(act_m_f, "k_act_m_f")
 #undef UP
-  if ((rc = upload_levels(b, "k_factor3", &b->T.factor3)) || (rc = upload_levels(b, "k_linv", &b->T.linv))) { rr_batch_destroy(b); return rc; }
+  {
+    const uint32_t qb = (uint32_t)m->kd.o_qLD * 4u, ab = (uint32_t)m->kd.o_xpos * 4u, nM = (uint32_t)m->dims.nM;
+    if ((rc = upload_levels(b, m->solver == 2 ? "k_factor3p" : "k_factor3", &b->T.factor3, qb, ab, nM)) || (rc = upload_levels(b, "k_linv", &b->T.linv, qb, ab, nM))) { rr_batch_destroy(b); return rc; }
+  }
   memset(&b->T_rep, 0, sizeof(b->T_rep));
   if (m->pair_ok) {      // tables of one replica; the level schedules twice (second copy addressed into the second wavefront's region)
 #define UPH(field, name) if ((rc = upload(b, "h_" name, &b->T_rep.field))) { rr_batch_destroy(b); return rc; }
@@ -364,7 +374,8 @@ extern "C" int rr_batch_create(const rr_model* m, int32_t num_envs, int32_t devi
     UPH(act_f, "k_act_f") UPH(con_f, "k_con_f") UPH(root_mass, "k_root_mass")
 #undef UPH
     const uint32_t base = (uint32_t)m->kd_rep.o_qLD * 4u, rb = (uint32_t)m->kd_rep.lds_bytes_rep;
-    if ((rc = upload_levels(b, "h_k_factor3", &b->T_rep.factor3, base, 2, rb)) || (rc = upload_levels(b, "h_k_linv", &b->T_rep.linv, base, 2, rb))) { rr_batch_destroy(b); return rc; }
+    const uint32_t abase = (uint32_t)m->kd_rep.o_xpos * 4u, hnM = (uint32_t)m->kd_rep.nM;
+    if ((rc = upload_levels(b, "h_k_factor3", &b->T_rep.factor3, base, abase, hnM, 2, rb)) || (rc = upload_levels(b, "h_k_linv", &b->T_rep.linv, base, abase, hnM, 2, rb))) { rr_batch_destroy(b); return rc; }
     b->T_rep.anc4 = b->T_rep.M_ij_k;     // unused (Newton only); a valid pointer
   }
   {   // ancestor ids along the rows of M (Newton): byte Madr[i] + p = the p-th ancestor of dof i (p = 0: i itself)

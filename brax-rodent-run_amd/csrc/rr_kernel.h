@@ -49,6 +49,7 @@ struct RRDims {
   // 2 nv-dof model).  fac_stride / inv_stride (ints): PAIR instances hold a second copy of each level schedule behind the first, its
   // LDS addresses moved to the second wavefront's region.  lds_bytes_rep: LDS bytes of one replica's region
   int nv_scale, fac_stride, inv_stride, lds_bytes_rep;
+  int nalias;      // alias cells (pairs) of the factorisation schedule, at the head of the pose cells (levelsched.py); 0 for the Newton instances
   // debug dump offsets (floats)
   int g_xpos, g_xquat, g_xmat, g_com, g_cinert, g_crb, g_cdof, g_cvel, g_cfrc, g_qM, g_qLD, g_dinv, g_bias, g_passive,
       g_actuator, g_smooth, g_qacc_smooth, g_con_dist, g_con_pos, g_con_frame, g_con_D, g_con_aref, g_lim, g_qacc,
@@ -478,13 +479,12 @@ struct Wave {
     s_H = l + d.o_H; s_Mp = l + d.o_Mp; s_anc = (unsigned char*)(l + d.o_anc);
   }
 
-  // One wavefront owns the environment: its LDS instructions execute in program order, so a
-  // cross-lane hand-off through LDS needs no s_barrier and no vmcnt/lgkmcnt drain -- only that the
-  // compiler keeps the program order of the LDS accesses around this point.
-  // "memory" keeps the compiler from moving LDS accesses across; lgkmcnt(0) retires this wave's LDS operations
-  // (incl. the float atomics) without draining outstanding global table prefetches (no vmcnt wait).
+  // One wavefront owns the environment: its LDS instructions execute in program order, so a cross-lane hand-off through LDS
+  // needs no s_barrier and no lgkmcnt drain -- only that the compiler keeps the program order of the LDS accesses around this
+  // point ("memory" clobber).  Rounds 1-2 also retired the wave's LDS operations here (s_waitcnt lgkmcnt(0), a leftover of the
+  // float atomics); without it the results are bit-identical and the launch 1.2 % shorter (tools/variant_bench.py).
 #ifndef RR_SYNC_WAIT
-#define RR_SYNC_WAIT 1      // 0: compiler barrier only (experiment: the hardware's in-order LDS execution makes the wait redundant)
+#define RR_SYNC_WAIT 0      // 1: also retire the LDS operations at every hand-off (round 1-2 behaviour; bit-identical results, +1.2 % launch time)
 #endif
   __device__ __forceinline__ void sync() {
 #if RR_SYNC_WAIT
@@ -939,30 +939,34 @@ struct Wave {
     sync();
   }
 
-  // Executor of the level schedules of the factorisation and the inversion (rodent_amd/ktables.py pack_levels).  A table
-  // row is 64 independent QUAD operations on the sparse-matrix array s_qLD: four targets d_j -= a * b_j [/ piv], b_j four
-  // consecutive entries (the targets of one source row are consecutive entries of an ancestor row, so one shared operand,
-  // one reciprocal and one run of four feed four multiply-adds).  A lane accumulates over consecutive rows and, on a row
-  // flagged 1 (the flags are the same in every lane), stores d_j = d_j_old - sum_j: plain read-modify-writes -- within a
-  // level every target belongs to one lane and is written once, and no source of a level is written by that level.  The
-  // LDS reads of a row -- sources and old target values -- are therefore issued together, one LDS round trip per row of
-  // up to 256 multiply-adds; a level ends with one LDS hand-off (flag 2).  ATOMIC-FREE: an LDS float atomic costs ~10x a
-  // plain read-modify-write on gfx950 and >1000 cycles with every wave of the CU issuing them.  PREDICATE-FREE: the host
-  // turns the table's element indices into LDS byte addresses at upload, and empty operations / the unused targets of
-  // short runs address the cells ZERO (0.0), ONE (1.0) and TRASH kept behind the nM entries.
+  // Executor of the row schedules of the factorisation and the inversion (rodent_amd/levelsched.py).  A table row is 64
+  // independent QUAD operations on the sparse-matrix array s_qLD: four targets d_j -= a * b_j [/ piv], b_j four consecutive
+  // entries (the targets of one source row are consecutive entries of an ancestor row, so one shared operand, one reciprocal
+  // and one run of four feed four multiply-adds), applied as plain read-modify-writes: no two operations of a row share a
+  // target.  NO HAND-OFF BETWEEN ROWS: the LDS instructions of a wavefront execute in program order, so the reads of a row see
+  // every write of the rows before it, and all reads of a row are issued before its writes -- the host list-schedules the
+  // operations of a whole factorisation as one dependency graph under exactly these two rules (rounds 1-2 ran them level by
+  // level of the tree with a hand-off per level: 97 + 63 rows for the rodent, now 57 + 44).  The side branches of a fork
+  // accumulate into ALIAS copies of their ancestors' rows (pose cells, dead here), which one merge operation per quad folds
+  // in before the row is eliminated -- otherwise the free joint's rows, which every dof updates, serialise the schedule.
+  // ATOMIC-FREE: an LDS float atomic costs ~10x a plain read-modify-write on gfx950 and >1000 cycles with every wave of the
+  // CU issuing them.  PREDICATE-FREE: the host turns the table's element indices into LDS byte addresses at upload, and
+  // empty operations / the unused targets of short runs address the cells ZERO (0.0), ONE (1.0) and TRASH kept behind the
+  // nM entries (MINUS_ONE (-1.0) is the shared operand of a merge).
   // 1/piv: v_rcp_f32 refined by one Newton step (the row scaling by 1/D after the sweep uses the exact quotient).
-  // Rows (16 B per lane) are prefetched RR_RING ahead.
+  // Rows (16 B per lane) are prefetched RR_RING ahead; the table ends with RR_RING empty rows.
   typedef float __attribute__((address_space(3)))* rr_lf;
   static __device__ __forceinline__ float lds_ld(int byte_adr) { return *(rr_lf)(size_t)(unsigned)byte_adr; }
   static __device__ __forceinline__ void lds_st(int byte_adr, float v) { *(rr_lf)(size_t)(unsigned)byte_adr = v; }
   typedef int rr_v4i __attribute__((ext_vector_type(4)));
   // PAIRS: the step factorises two matrices of identical sparsity every substep -- M for the solver and
   // M + dt*diag(damping) for eulerdamp.  They are stored interleaved (float2 per entry), so one 8-byte LDS operation
-  // serves both: the table stream, the address extraction, the flags and the LDS round trip of a row are shared.
+  // serves both: the table stream, the address extraction and the LDS round trip of a row are shared.
   typedef rr_f2 __attribute__((address_space(3)))* rr_lf2;
   static __device__ __forceinline__ rr_f2 lds_ld2(int byte_adr) { return *(rr_lf2)(size_t)(unsigned)byte_adr; }
   static __device__ __forceinline__ void lds_st2(int byte_adr, rr_f2 v) { *(rr_lf2)(size_t)(unsigned)byte_adr = v; }
   // SHIFT: the schedules' LDS addresses are baked for the pair array at o_qLD; `delta` (bytes) moves them to another pair array
+  // (alias-free schedules only: the alias cells are not part of the array)
   template <bool DIV, bool SHIFT = false>
   __device__ __forceinline__ void run_levels(rr_gi table, int nrows, int delta = 0) {
     typedef const rr_v4i __attribute__((address_space(1)))* rr_gv4;
@@ -970,10 +974,10 @@ struct Wave {
     rr_v4i ring[RR_RING];
 #pragma unroll
     for (int u = 0; u < RR_RING; ++u) ring[u] = tab[u * RR_LANES + lane];
-    rr_f2 acc[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
     for (int r0 = 0; r0 < nrows; r0 += RR_RING) {
 #pragma unroll
       for (int u = 0; u < RR_RING; ++u) {
+        if (u && r0 + u >= nrows) break;            // wave-uniform: the schedule need not fill its last ring
         const rr_v4i e = ring[u];
         ring[u] = tab[(r0 + RR_RING + u) * RR_LANES + lane];
         const int sh = SHIFT ? delta : 0;
@@ -981,47 +985,35 @@ struct Wave {
         const int d8[4] = {(e.y & 0xFFFF) + sh, (int)((unsigned)e.y >> 16) + sh, (e.z & 0xFFFF) + sh, (int)((unsigned)e.z >> 16) + sh};
         const rr_f2 va = lds_ld2(a8);
         rr_f2 vp = {1.0f, 1.0f};
-        if (DIV) vp = lds_ld2(a8 - (e.w & 0xFFFF) + 8);
-        const int fl = __builtin_amdgcn_readfirstlane(e.w) >> 16;
+        if (DIV) vp = lds_ld2(a8 - e.w + 8);
         rr_f2 vb[4], vo[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) vb[j] = lds_ld2(b8 + 8 * j);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) vo[j] = lds_ld2(d8[j]);    // also on rows that do not apply: reading the targets only on the flagged rows measured +2.2 % (late reads)
+        for (int j = 0; j < 4; ++j) vo[j] = lds_ld2(d8[j]);
         rr_f2 t = va;
         if (DIV) {
           rr_f2 r = {__builtin_amdgcn_rcpf(vp.x), __builtin_amdgcn_rcpf(vp.y)};
           r = r * (2.0f - vp * r);
           t *= r;
         }
-        if (DIV) {       // several contribution ranks per target: accumulate, apply on the flagged row
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j] += vb[j] * t;
-          if (fl & 1) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { lds_st2(d8[j], vo[j] - acc[j]); acc[j] = rr_f2{0.0f, 0.0f}; }
-          }
-        } else {         // inversion: one contribution per target and level, every row applies
-#pragma unroll
-          for (int j = 0; j < 4; ++j) lds_st2(d8[j], vo[j] - vb[j] * t);
-        }
-        if (fl & 2) sync();
+        for (int j = 0; j < 4; ++j) lds_st2(d8[j], vo[j] - vb[j] * t);
       }
     }
   }
 
   // sparse L'DL in place in s_qLD  [MuJoCo mj_factorM]; damp = dt for the eulerdamp matrix M + dt*diag(damping).
-  // Level-parallel: all dofs k of one depth level are eliminated together (their rows are final: only deeper dofs update
-  // them).  The rank-1 updates of a level are grouped by TARGET entry (k_factor3): a lane owns one target per group of 64
-  // targets and sums its contributions L_kp L_kq / D_k over the level's dofs k below it, one table row per contribution
-  // rank.  Rows are scaled by 1/D afterwards.
+  // The rank-1 updates M[anc_p][anc_q] -= M[k][anc_p] M[k][anc_q] / M[k][k] of all dofs k, as quad operations in the row order
+  // of k_factor3 (run_levels); rows are scaled by 1/D afterwards.
   // Both matrices at once: entry e of the array is the pair (M_e, M_e + dt*damping on the diagonal); mass_matrix has
   // written both halves, the damping is added here.  (M itself is not needed afterwards: the one product with M of the
   // substep, M * qacc_warmstart, is taken before.)
   __device__ __forceinline__ void factor() {
     int ment[NME];          // for the row scaling at the end; requested now, local to this call (not held across the solver)
     load_ment(ment);
-    if (lane < 8) s_qLD[2 * D.nM + lane] = (lane >> 1) == 1 ? 1.0f : 0.0f;     // cells ZERO, ONE, TRASH (+ pad) of the level schedules
+    if (lane < 8) s_qLD[2 * D.nM + lane] = (lane >> 1) == 1 ? 1.0f : ((lane >> 1) == 3 ? -1.0f : 0.0f);     // cells ZERO, ONE, TRASH, MINUS_ONE of the row schedules
+    for (int c = lane; c < 2 * D.nalias; c += RR_LANES) s_buf[c] = 0.0f;      // alias copies of the hot rows (levelsched.py): pose cells, dead from here to the row scaling
 #pragma unroll
     for (int s = 0; s < NVS; ++s) {
       const int d = lane + RR_LANES * s;

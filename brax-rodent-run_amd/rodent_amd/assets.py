@@ -22,8 +22,8 @@ def asset_path(name: str) -> str:
 
 
 def _compiler_mtime() -> float:
-    from . import ktables
-    return max(os.path.getmtime(mjcf.__file__), os.path.getmtime(ktables.__file__))
+    from . import ktables, levelsched
+    return max(os.path.getmtime(mjcf.__file__), os.path.getmtime(ktables.__file__), os.path.getmtime(levelsched.__file__))
 
 
 def build_assets(xml_dir: str, names=MODELS, force: bool = False):

@@ -269,91 +269,18 @@ def build_kernel_tables(m):
     if 8 * (nM + 20) >= 65536 or nv >= 255:
         raise ValueError("nM above the 12-bit address field of the solve job tables")
 
-    # ---- atomic-free factorisation and inversion schedules.  Both are lists of LEVELS; a level is a list of table rows
-    # of 64 independent QUAD operations on the sparse-matrix array: four targets d0..d3 -= src_a * src_(b0 + j) [/ piv],
-    # j = 0..3 -- the targets of one source row are consecutive entries of an ancestor row, so one shared operand and one
-    # run of four feed four multiply-adds.  No source of a level is written inside the level, so the kernel issues the LDS
-    # reads of RR_BLK rows (one block) together.  Levels are padded to whole blocks.
-    # Operation = 4 ints:  x = a | b0 << 16,  y = d0 | d1 << 16,  z = d2 | d3 << 16,  w = q | flags << 8  (element indices;
-    # piv = a + 1 - q).  The array has extra cells ZERO = nM (0.0), ONE = nM + 1 (1.0), TRASH = nM + 2 (and one pad): an
-    # empty operation is a = b0 = ZERO, q = 0 (piv = ONE), d* = TRASH, a short run sends its unused targets to TRASH, so the
-    # kernel needs no predicates.  flags: 1 = apply the lane's accumulated sums to d*, 2 = level ends (LDS hand-off); they
-    # are the same in all 64 lanes of a row.
-    ZERO, TRASH = nM, nM + 2
-    BLK, RING = 1, 8          # rows per block (RR_BLK), rows in flight (RR_RING)
-
-    def quads(a_, b_start, d_start, n, q_):
-        """cut a run of n consecutive (source b, target d) pairs sharing the operand a_ into quad operations"""
-        out = []
-        for j0 in range(0, n, 4):
-            m_ = min(4, n - j0)
-            out.append((a_, b_start + j0, tuple(d_start + j0 + j if j < m_ else TRASH for j in range(4)), q_))
-        return out
-
-    def pack_levels(levels):
-        def word(fl, op=None):
-            if op is None:
-                return (ZERO | (ZERO << 16), TRASH | (TRASH << 16), TRASH | (TRASH << 16), fl << 8)
-            a_, b_, d_, q_ = op
-            if a_ is None:                                          # no contribution on this rank; targets kept
-                a_, b_, q_ = ZERO, ZERO, 0
-            return (a_ | (b_ << 16), d_[0] | (d_[1] << 16), d_[2] | (d_[3] << 16), q_ | (fl << 8))
-        rows = []
-        for lv in levels:
-            if not lv:
-                continue
-            lv = list(lv)
-            while len(lv) % BLK:
-                lv.append(([], 0))
-            for t, (ops, fl) in enumerate(lv):
-                if t == len(lv) - 1:
-                    fl |= 2
-                row = np.array([word(fl)] * LANES, np.int64)
-                for ln, op in enumerate(ops):
-                    row[ln] = word(fl, op)
-                rows.append(row)
-        empty = np.array([word(0)] * LANES, np.int64)
-        while len(rows) % RING:                               # the kernel consumes RING rows per loop trip
-            rows.append(empty)
-        nrows = len(rows)
-        rows += [empty] * RING                                # slack rows the ring may prefetch
-        return (np.stack(rows) & 0xFFFFFFFF).astype(np.uint32).view(np.int32), np.int32(nrows)
-
-    # factorisation [MuJoCo mj_factorM], deep -> shallow: the rank-1 updates of a level are grouped by TARGET quad.  A lane
-    # owns one quad of targets per group of 64 and accumulates its contributions L_kp L_kq / D_k over the dofs k of the
-    # level below it, one row per contribution rank; the last rank applies the sums with plain read-modify-writes.
-    levels = []
-    for l in range(dmax, 0, -1):
-        tgt = {}
-        for kk in by_level[l]:
-            chain = anc[anc_adr[kk]:anc_adr[kk + 1]][::-1]
-            for p in range(1, l + 1):                              # targets (anc_p, anc_q), q = p..l: consecutive entries
-                for op in quads(int(Madr[kk] + p), int(Madr[kk] + p), int(Madr[int(chain[p])]), l - p + 1, p + 1):
-                    tgt.setdefault(op[2], []).append(op)
-        order = sorted(tgt, key=lambda d_: (-len(tgt[d_]), d_))          # equal multiplicities share a group
-        lv = []
-        for g0 in range(0, len(order), LANES):
-            grp = order[g0:g0 + LANES]
-            mult = max(len(tgt[d_]) for d_ in grp)
-            for t in range(mult):
-                lv.append(([tgt[d_][t] if t < len(tgt[d_]) else (None, None, d_, 0) for d_ in grp], 1 if t == mult - 1 else 0))
-        levels.append(lv)
-    k["k_factor3"], k["k_factor3_rows"] = pack_levels(levels)
-
-    # inversion W = I - L^-1 (strictly lower part, same tree sparsity as L), in place, shallow -> deep, Gauss-Jordan by
-    # levels: when the dofs k of a level are processed, every descendant row i does W_ia -= W_ik W_ka for the strict
-    # ancestors a of k (consecutive entries of rows i and k).  W_ik still holds L_ik (only deeper levels write it), row k is
-    # final, and each target is written once per level.  The triangular solves then are two independent sparse products
-    # (see Wave::ldl_solve).
-    levels = []
-    for l in range(1, dmax):
-        ops = []
-        for kk in by_level[l]:
-            for i in range(kk + 1, int(last_desc[kk]) + 1):
-                mk = int(Madr[i] + ddepth[i] - l)                     # W_ik; the targets (i, a) follow it, deepest a first
-                ops += quads(mk, int(Madr[kk] + 1), mk + 1, l, 0)
-        levels.append([(ops[r0:r0 + LANES], 1) for r0 in range(0, len(ops), LANES)])
-    k["k_linv"], k["k_linv_rows"] = pack_levels(levels)
+    # ---- atomic-free factorisation and inversion schedules (levelsched.py): table rows of 64 independent QUAD operations on the
+    # sparse-matrix array, four targets d0..d3 -= src_a * src_(b0 + j) [/ piv], j = 0..3 -- the targets of one source row are
+    # consecutive entries of an ancestor row, so one shared operand and one run of four feed four multiply-adds.  The operations
+    # of each schedule are list-scheduled as ONE dependency graph (a row sees what earlier rows wrote: the LDS instructions of a
+    # wavefront execute in order), the side branches of a fork accumulating into private alias copies of their ancestors' rows.
+    # Operation = 4 ints:  x = a | b0 << 16,  y = d0 | d1 << 16,  z = d2 | d3 << 16,  w = q  (element indices; piv = a + 1 - q).
+    # Cells behind the nM entries: ZERO = nM (0.0), ONE = nM + 1 (1.0), TRASH = nM + 2, MINUS_ONE = nM + 3 (-1.0), alias cells from
+    # nM + 4 (k_nalias of them; the host maps them to the pose cells, dead during the factorisation): an empty operation is
+    # a = b0 = ZERO, q = 0 (piv = ONE), d* = TRASH, a short run sends its unused targets to TRASH, so the kernel needs no predicates.
+    RING = 8                  # rows in flight (RR_RING): that many empty rows follow each schedule
+    from . import levelsched
+    k.update(levelsched.build(ddepth, Madr, dpar, last_desc, nM, alias_cells=max(7 * nb + 4, 6 * nv) // 2, ring=RING))
 
     # ---- balanced jobs of the two sparse products of the solve (Wave::ldl_solve).  Column product (U' b): column j sums
     # over its descendants i = j+1 .. last_desc[j]; row product (U y): row i sums over its ancestors p = 1 .. depth[i].  Both

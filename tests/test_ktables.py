@@ -73,67 +73,57 @@ def test_mulm_by_solve_jobs(model_and_state):
     np.testing.assert_allclose(qM[Madr] * x + col + row, Md @ x, rtol=1e-12, atol=1e-14)
 
 
-BLK = 1         # rows per block of the level schedules (RR_BLK)
 RING = 8        # rows in flight (RR_RING)
 
 
-def run_levels(L, tab, nrows, div):
-    """numpy restatement of Wave::run_levels: blocks of BLK rows of quad operations; all reads of a block (sources and the
-    old target values) are taken before its writes; a level's sources are never written inside the level.  L carries the
-    extra cells ZERO, ONE, TRASH (+ pad) behind its nM entries."""
-    nM = len(L) - 4
-    assert L[nM] == 0.0 and L[nM + 1] == 1.0
-    acc = np.zeros((LANES, 4))
-    written, read = set(), set()
-    assert nrows % RING == 0 and tab.shape[0] == nrows + RING
+def _cells(nM, nalias):
+    """[ZERO, ONE, TRASH, MINUS_ONE] + zeroed alias cells + 4 spare cells"""
+    return np.concatenate([[0.0, 1.0, 0.0, -1.0], np.zeros(nalias + 4)])
+
+
+def run_rows(L, nM, tab, nrows, div):
+    assert L[nM] == 0.0 and L[nM + 1] == 1.0 and L[nM + 3] == -1.0
+    assert tab.shape[0] == nrows + RING                     # RING empty rows follow: the executor prefetches that far
     u32 = tab.view(np.uint32).astype(np.int64)
-    for b0 in range(0, nrows, BLK):
-        snap = L.copy()                                   # what the block's batched reads see
-        for u in range(BLK):
-            e = u32[b0 + u]
-            fl = int(e[0, 3] >> 8)
-            assert np.all((e[:, 3] >> 8) == fl) and 0 <= fl < 4
-            a, b_ = e[:, 0] & 0xFFFF, e[:, 0] >> 16
-            d = np.stack([e[:, 1] & 0xFFFF, e[:, 1] >> 16, e[:, 2] & 0xFFFF, e[:, 2] >> 16], axis=1)
-            q = e[:, 3] & 0xFF
-            real = a != nM
-            assert np.all(b_[~real] == nM) and np.all(q[~real] == 0)
-            valid = d < nM                                # targets of short runs and of empty operations go to TRASH
-            assert np.all(d[~valid] == nM + 2) and np.all(valid[real, 0])
-            assert np.all(valid[:, :-1] >= valid[:, 1:])  # the valid targets of a quad come first
-            read.update(a[real].tolist())
-            for j in range(4):
-                read.update((b_ + j)[valid[:, j] & real].tolist())
-            if div:
-                piv = a + 1 - q
-                assert np.all(piv[~real] == nM + 1) and np.all(piv[real] < nM)
-                read.update(piv[real].tolist())
-                t = snap[a] / snap[piv]
-            else:
-                assert np.all(q == 0)
-                t = snap[a]
-            assert np.all(b_[real] + 3 < len(L))
-            for j in range(4):
-                acc[:, j] += snap[np.minimum(b_ + j, len(L) - 1)] * t
-            if fl & 1 or not div:
-                tg = d[valid]
-                assert len(set(tg.tolist())) == len(tg)   # plain RMW: no two lanes / slots share a target
-                assert not (set(tg.tolist()) & written)   # one write per target and level
-                written.update(tg.tolist())
-                L[tg] = snap[tg] - acc[valid]
-                acc[:] = 0.0
-                L[nM:] = [0.0, 1.0, 0.0, 0.0]             # whatever landed in TRASH is never used
-            assert not (fl & 2) or u == BLK - 1           # levels end at block ends
-            if fl & 2:
-                assert not (written & read)               # reads of a level never see its writes
-                assert np.all(acc == 0.0)
-                written, read = set(), set()
-    return L
+    used = 0
+    for r in range(nrows + RING):
+        e = u32[r]
+        a, b_ = e[:, 0] & 0xFFFF, e[:, 0] >> 16
+        d = np.stack([e[:, 1] & 0xFFFF, e[:, 1] >> 16, e[:, 2] & 0xFFFF, e[:, 2] >> 16], axis=1)
+        q = e[:, 3]
+        assert np.all(q < 256)                               # no flags: rows carry no hand-offs
+        real = a != nM
+        if r >= nrows:
+            assert not real.any()
+            continue
+        used += int(real.sum())
+        assert np.all(b_[~real] == nM) and np.all(q[~real] == 0) and np.all(d[~real] == nM + 2)
+        valid = d != nM + 2                                  # targets of short runs and of empty operations go to TRASH
+        assert np.all(valid[real, 0]) and np.all(valid[:, :-1] >= valid[:, 1:])      # the valid targets of a quad come first
+        assert np.all(b_[real] + 3 < len(L)) and np.all(d < len(L) - 4)
+        snap = L.copy()                                      # what the row's reads see
+        if div:
+            piv = a + 1 - q
+            assert np.all(piv[~real] == nM + 1)
+            t = snap[a] / snap[piv]
+        else:
+            assert np.all(q == 0)
+            t = snap[a]
+        tg = d[valid]
+        assert len(set(tg.tolist())) == len(tg)              # plain read-modify-writes: no two lanes / slots share a target
+        for j in range(4):
+            v = valid[:, j]
+            L[d[v, j]] = snap[d[v, j]] - snap[b_[v] + j] * t[v]
+        L[nM:nM + 4] = [0.0, 1.0, 0.0, -1.0]                 # whatever landed in TRASH is never used
+    return L, used
 
 
-def kernel_factor(m, qM):
-    """numpy restatement of Wave::factor: gather rows by target entry (k_factor3), then the row scaling by 1/D."""
-    L = run_levels(np.concatenate([qM, [0.0, 1.0, 0.0, 0.0]]), m["k_factor3"], int(m["k_factor3_rows"]), True)[:len(qM)]
+def kernel_factor(m, qM, plain=False):
+    """numpy restatement of Wave::factor: the row schedule k_factor3 (with alias copies; k_factor3p without), then the row scaling by 1/D."""
+    nM = len(qM)
+    name, nalias = ("k_factor3p", 0) if plain else ("k_factor3", int(m["k_nalias"]))
+    L, used = run_rows(np.concatenate([qM, _cells(nM, nalias)]), nM, m[name], int(m[name + "_rows"]), True)
+    L = L[:nM]
     Madr = m["k_dof_i"][:, 4]
     dinv = 1.0 / L[Madr]
     ij = m["k_M_ij"]
@@ -145,7 +135,8 @@ def kernel_factor(m, qM):
 
 def kernel_invert(m, L):
     """numpy restatement of Wave::invert: W = I - L^-1 in place (k_linv)."""
-    return run_levels(np.concatenate([L, [0.0, 1.0, 0.0, 0.0]]), m["k_linv"], int(m["k_linv_rows"]), False)[:len(L)]
+    nM = len(L)
+    return run_rows(np.concatenate([L, _cells(nM, 0)]), nM, m["k_linv"], int(m["k_linv_rows"]), False)[0][:nM]
 
 
 def kernel_solve(m, W, dinv, b):
@@ -161,9 +152,10 @@ def kernel_solve(m, W, dinv, b):
 def test_factor_and_solve_tables(model_and_state):
     m, M, d = model_and_state
     qM, qLD = d.get("qM"), d.get("qLD")
-    L, dinv = kernel_factor(m, qM)
-    np.testing.assert_allclose(L, qLD, rtol=1e-9, atol=1e-16)
-    np.testing.assert_allclose(dinv, d.get("qLDiagInv"), rtol=1e-9)
+    for plain in (True, False):        # the alias-free schedule (Newton instances) and the one with alias copies of the hot rows
+        L, dinv = kernel_factor(m, qM, plain)
+        np.testing.assert_allclose(L, qLD, rtol=1e-9, atol=1e-16)
+        np.testing.assert_allclose(dinv, d.get("qLDiagInv"), rtol=1e-9)
     U = kernel_invert(m, L)
     Ld = np.eye(M.nv)
     ij = m["k_M_ij"]
