@@ -20,6 +20,9 @@
 #define RR_LANES 64
 #define RR_DOFI 12   // ints per dof in k_dof_i
 #define RR_BODYI 12  // ints per body in k_body_i
+#ifndef RR_WIDE
+#define RR_WIDE 1
+#endif
 #define RR_RING 8    // rows of a level schedule in flight (ktables RING); 12 / 16 measured 2-3 % slower in round 2
 
 #define RR_NPH 24    // phases of the diagnostic (s_memtime) build
@@ -967,30 +970,77 @@ struct Wave {
   static __device__ __forceinline__ void lds_st2(int byte_adr, rr_f2 v) { *(rr_lf2)(size_t)(unsigned)byte_adr = v; }
   // SHIFT: the schedules' LDS addresses are baked for the pair array at o_qLD; `delta` (bytes) moves them to another pair array
   // (alias-free schedules only: the alias cells are not part of the array)
+  struct RowAdr { int a8, p8, b8, d8[4]; };
+  template <bool DIV, bool SHIFT>
+  static __device__ __forceinline__ RowAdr row_adr(const rr_v4i& e, int delta) {
+    const int sh = SHIFT ? delta : 0;
+    RowAdr r;
+    r.a8 = (e.x & 0xFFFF) + sh; r.b8 = (int)((unsigned)e.x >> 16) + sh;
+    r.p8 = DIV ? r.a8 - e.w + 8 : 0;
+    r.d8[0] = (e.y & 0xFFFF) + sh; r.d8[1] = (int)((unsigned)e.y >> 16) + sh; r.d8[2] = (e.z & 0xFFFF) + sh; r.d8[3] = (int)((unsigned)e.z >> 16) + sh;
+    return r;
+  }
   template <bool DIV, bool SHIFT = false>
   __device__ __forceinline__ void run_levels(rr_gi table, int nrows, int delta = 0) {
     typedef const rr_v4i __attribute__((address_space(1)))* rr_gv4;
-    rr_gv4 tab = (rr_gv4)table;
+    typedef const char __attribute__((address_space(1)))* rr_gc;
+    const rr_gc tab = (rr_gc)table;                         // wave-uniform base + 16 * lane: the row's address needs no vector arithmetic
+    const unsigned lane16 = 16u * (unsigned)lane;
+    constexpr int ROWB = RR_LANES * 16;
     rr_v4i ring[RR_RING];
 #pragma unroll
-    for (int u = 0; u < RR_RING; ++u) ring[u] = tab[u * RR_LANES + lane];
+    for (int u = 0; u < RR_RING; ++u) ring[u] = *(rr_gv4)(tab + u * ROWB + lane16);
+    RowAdr cur = row_adr<DIV, SHIFT>(ring[0], delta);
     for (int r0 = 0; r0 < nrows; r0 += RR_RING) {
+      const rr_gc nxt_rows = tab + (size_t)(r0 + RR_RING) * ROWB;
 #pragma unroll
+#if RR_WIDE == 2
+      // EXPERIMENT: table rows in pairs -- the reads of both rows before the writes of either (a row of 128 operations, two per lane)
+      for (int u = 0; u < RR_RING; u += 2) {
+        if (u && r0 + u >= nrows) break;
+        const RowAdr c0 = cur, c1 = row_adr<DIV, SHIFT>(ring[u + 1], delta);
+        const rr_f2 va0 = lds_ld2(c0.a8), va1 = lds_ld2(c1.a8);
+        rr_f2 vp0 = {1.0f, 1.0f}, vp1 = {1.0f, 1.0f};
+        if (DIV) { vp0 = lds_ld2(c0.p8); vp1 = lds_ld2(c1.p8); }
+        rr_f2 vb0[4], vo0[4], vb1[4], vo1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vb0[j] = lds_ld2(c0.b8 + 8 * j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vo0[j] = lds_ld2(c0.d8[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vb1[j] = lds_ld2(c1.b8 + 8 * j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vo1[j] = lds_ld2(c1.d8[j]);
+        ring[u] = *(rr_gv4)(nxt_rows + u * ROWB + lane16);
+        ring[u + 1] = *(rr_gv4)(nxt_rows + (u + 1) * ROWB + lane16);
+        const RowAdr nxt = row_adr<DIV, SHIFT>(ring[(u + 2) % RR_RING], delta);
+        rr_f2 t0 = va0, t1 = va1;
+        if (DIV) {
+          rr_f2 r0_ = {__builtin_amdgcn_rcpf(vp0.x), __builtin_amdgcn_rcpf(vp0.y)}, r1_ = {__builtin_amdgcn_rcpf(vp1.x), __builtin_amdgcn_rcpf(vp1.y)};
+          r0_ = r0_ * (2.0f - vp0 * r0_); r1_ = r1_ * (2.0f - vp1 * r1_);
+          t0 *= r0_; t1 *= r1_;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_st2(c0.d8[j], vo0[j] - vb0[j] * t0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_st2(c1.d8[j], vo1[j] - vb1[j] * t1);
+        cur = nxt;
+      }
+      if (true) continue;
+#endif
       for (int u = 0; u < RR_RING; ++u) {
         if (u && r0 + u >= nrows) break;            // wave-uniform: the schedule need not fill its last ring
-        const rr_v4i e = ring[u];
-        ring[u] = tab[(r0 + RR_RING + u) * RR_LANES + lane];
-        const int sh = SHIFT ? delta : 0;
-        const int a8 = (e.x & 0xFFFF) + sh, b8 = (int)((unsigned)e.x >> 16) + sh;
-        const int d8[4] = {(e.y & 0xFFFF) + sh, (int)((unsigned)e.y >> 16) + sh, (e.z & 0xFFFF) + sh, (int)((unsigned)e.z >> 16) + sh};
-        const rr_f2 va = lds_ld2(a8);
+        const rr_f2 va = lds_ld2(cur.a8);
         rr_f2 vp = {1.0f, 1.0f};
-        if (DIV) vp = lds_ld2(a8 - e.w + 8);
+        if (DIV) vp = lds_ld2(cur.p8);
         rr_f2 vb[4], vo[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) vb[j] = lds_ld2(b8 + 8 * j);
+        for (int j = 0; j < 4; ++j) vb[j] = lds_ld2(cur.b8 + 8 * j);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) vo[j] = lds_ld2(d8[j]);
+        for (int j = 0; j < 4; ++j) vo[j] = lds_ld2(cur.d8[j]);
+        // under the latency of these reads: the ring's refill and the NEXT row's addresses (ring[u + 1] arrived rows ago)
+        ring[u] = *(rr_gv4)(nxt_rows + u * ROWB + lane16);
+        const RowAdr nxt = row_adr<DIV, SHIFT>(ring[(u + 1) % RR_RING], delta);
         rr_f2 t = va;
         if (DIV) {
           rr_f2 r = {__builtin_amdgcn_rcpf(vp.x), __builtin_amdgcn_rcpf(vp.y)};
@@ -998,7 +1048,8 @@ struct Wave {
           t *= r;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) lds_st2(d8[j], vo[j] - vb[j] * t);
+        for (int j = 0; j < 4; ++j) lds_st2(cur.d8[j], vo[j] - vb[j] * t);
+        cur = nxt;
       }
     }
   }

@@ -280,7 +280,12 @@ def build_kernel_tables(m):
     # a = b0 = ZERO, q = 0 (piv = ONE), d* = TRASH, a short run sends its unused targets to TRASH, so the kernel needs no predicates.
     RING = 8                  # rows in flight (RR_RING): that many empty rows follow each schedule
     from . import levelsched
-    k.update(levelsched.build(ddepth, Madr, dpar, last_desc, nM, alias_cells=max(7 * nb + 4, 6 * nv) // 2, ring=RING))
+    # where the host puts the two regions (csrc/rr_kernel.h rr_layout, float offsets; used for the lane assignment's bank model only)
+    up4 = lambda x: (x + 3) // 4 * 4
+    o_xpos = up4(int(m["nq"])) + up4(nv + 1) + 2 * up4(int(m["nu"]))
+    o_qLD = o_xpos + up4(max(7 * nb + 4, 6 * nv)) + up4(10 * nb) + up4(6 * nv + 6) + up4(6 * nb)
+    k.update(levelsched.build(ddepth, Madr, dpar, last_desc, nM, alias_cells=max(7 * nb + 4, 6 * nv) // 2, ring=RING,
+                              matrix_slot=o_qLD // 2, alias_slot=o_xpos // 2))
 
     # ---- balanced jobs of the two sparse products of the solve (Wave::ldl_solve).  Column product (U' b): column j sums
     # over its descendants i = j+1 .. last_desc[j]; row product (U y): row i sums over its ancestors p = 1 .. depth[i].  Both

@@ -278,7 +278,92 @@ def check(ops, rows, width: int = LANES):
         assert all(row_of[d] < row_of[t] for d in g.raw[t]) and all(row_of[d] <= row_of[t] for d in g.war[t])
 
 
-def pack(tr: Tree, ops, rows, ring: int):
+def _split_wide(rows, width):
+    """EXPERIMENT (RR_SCHED_WIDTH=128): a row of up to 128 operations becomes two consecutive table rows the executor treats as one"""
+    if width <= LANES:
+        return rows
+    out = []
+    for row in rows:
+        out.append(row[:LANES]); out.append(row[LANES:])
+    return out
+
+
+class Banks:
+    """8-byte LDS slot of an element index, up to a common constant: matrix cells from `matrix_slot`, alias cells from `alias_slot`
+    (the host's layout, csrc/rr_kernel.h rr_layout; only their difference mod 32 matters, and only for timing)."""
+
+    def __init__(self, tr: Tree, matrix_slot: int = 0, alias_slot: int = 0):
+        self.a0, self.m0, self.a_s = tr.ALIAS0, matrix_slot, alias_slot
+
+    def slot(self, e):
+        return self.m0 + e if e < self.a0 else self.a_s + e - self.a0
+
+
+def _half_read_cycles(words, bk: Banks, div: bool):
+    """LDS-array cycles of a row's reads for one 32-lane half [MI355X guide: ds_read_b64 is served per half, bank = 8-byte slot mod 32,
+    equal addresses broadcast, every further address on a busy bank costs a cycle]"""
+    streams = [[bk.slot(w[0]) for w in words]]
+    if div:
+        streams.append([bk.slot(w[0] + 1 - w[3]) for w in words])
+    for j in range(4):
+        streams.append([bk.slot(w[1] + j) for w in words])
+        streams.append([bk.slot(w[2][j]) for w in words])
+    c = 0
+    for st in streams:
+        cnt = {}
+        for x in set(st):
+            cnt[x & 31] = cnt.get(x & 31, 0) + 1
+        c += max(cnt.values()) if cnt else 0
+    return c
+
+
+def assign_lanes(ops, row, bk: Banks, div: bool, sweeps: int = 2):
+    """Which lane runs which operation of a row -- free for correctness, not for the LDS: `ds_write_b64` is served in groups of 16
+    consecutive lanes with bank = 8-byte slot mod 16, so a quarter of the wave writes conflict-free when the first targets of its
+    16 quads lie in 16 different slot classes (the other three targets follow).  The operations of each class are spread over the four
+    quarters; operations of one class then swap quarters while that lowers the modelled read cycles of the two halves.
+    -> 64 entries: operation index or None."""
+    cls = {}
+    for t in row:
+        cls.setdefault(bk.slot(ops[t].word[2][0]) & 15, []).append(t)
+    Q = [[] for _ in range(4)]
+    over = []
+    for c, ts in sorted(cls.items(), key=lambda kv: (-len(kv[1]), kv[0])):
+        qs = sorted(range(4), key=lambda q: (len(Q[q]), q))
+        for i, t in enumerate(ts):
+            if i < 4 and len(Q[qs[i]]) < 16:
+                Q[qs[i]].append(t)
+            else:
+                over.append(t)
+    for t in over:
+        Q[min(range(4), key=lambda q: (len(Q[q]), q))].append(t)
+    assert all(len(q) <= 16 for q in Q)
+
+    def cost():
+        return (_half_read_cycles([ops[t].word for t in Q[0] + Q[1]], bk, div) +
+                _half_read_cycles([ops[t].word for t in Q[2] + Q[3]], bk, div))
+    best = cost()
+    for _ in range(sweeps):
+        for c in sorted(cls):
+            pos = [(q, i) for q in range(4) for i, t in enumerate(Q[q]) if bk.slot(ops[t].word[2][0]) & 15 == c]
+            for x in range(len(pos)):
+                for y in range(x + 1, len(pos)):
+                    (qa, ia), (qb, ib) = pos[x], pos[y]
+                    if qa >> 1 == qb >> 1:
+                        continue                      # same half: the reads do not change
+                    Q[qa][ia], Q[qb][ib] = Q[qb][ib], Q[qa][ia]
+                    v = cost()
+                    if v < best:
+                        best = v
+                    else:
+                        Q[qa][ia], Q[qb][ib] = Q[qb][ib], Q[qa][ia]
+    lanes = []
+    for q in Q:
+        lanes += q + [None] * (16 - len(q))
+    return lanes
+
+
+def pack(tr: Tree, ops, rows, ring: int, bk: Banks = None, div: bool = True):
     """rows of 64 x 4 ints:  x = a | b0 << 16,  y = d0 | d1 << 16,  z = d2 | d3 << 16,  w = q  (piv = a + 1 - q);  an empty slot is
     a = b0 = ZERO, piv = ONE, targets TRASH.  `ring` empty rows follow (the executor prefetches that far ahead)."""
     Z, T = tr.ZERO, tr.TRASH
@@ -286,20 +371,26 @@ def pack(tr: Tree, ops, rows, ring: int):
     out = np.empty((len(rows) + ring, LANES, 4), np.int64)
     out[:] = empty
     for r, row in enumerate(rows):
-        for ln, t in enumerate(row):
+        lanes = assign_lanes(ops, row, bk, div) if bk is not None else row
+        for ln, t in enumerate(lanes):
+            if t is None:
+                continue
             a, b0, d, q = ops[t].word
             assert 0 <= q < 256 and max(a, b0 + 3, *d) < 65536
             out[r, ln] = (a | (b0 << 16), d[0] | (d[1] << 16), d[2] | (d[3] << 16), q)
     return (out & 0xFFFFFFFF).astype(np.uint32).view(np.int32), np.int32(len(rows))
 
 
-def build(ddepth, Madr, dpar, last_desc, nM, alias_cells: int, ring: int):
+def build(ddepth, Madr, dpar, last_desc, nM, alias_cells: int, ring: int, matrix_slot: int = 0, alias_slot: int = 0):
     """-> dict of tables: k_factor3 (with alias copies, k_nalias cells), k_factor3p (plain: Newton's Hessian reuses the schedule on a
     second array, which has no alias region), k_linv, and their row counts."""
     tr = Tree(ddepth, Madr, dpar, last_desc, nM)
+    bk = Banks(tr, matrix_slot, alias_slot)
     cand = alias_candidates(tr)
     plain_ops, _ = factor_ops(tr)
-    plain = schedule(plain_ops)
+    import os
+    W = int(os.environ.get("RR_SCHED_WIDTH", LANES))
+    plain = schedule(plain_ops, W)
     best = (len(plain), 0, plain_ops, plain)
     tried = []
     shallow = [c for c in cand if cand and len(c[1]) == len(cand[0][1])]
@@ -310,13 +401,13 @@ def build(ddepth, Madr, dpar, last_desc, nM, alias_cells: int, ring: int):
         ops, nalias = factor_ops(tr, groups)
         if nalias + 4 > alias_cells:
             continue
-        rows = schedule(ops)
+        rows = schedule(ops, W)
         if (len(rows), nalias) < best[:2]:
             best = (len(rows), nalias, ops, rows)
     k = {}
-    k["k_factor3"], k["k_factor3_rows"] = pack(tr, best[2], best[3], ring)
+    k["k_factor3"], k["k_factor3_rows"] = pack(tr, best[2], _split_wide(best[3], W), ring, bk, True)
     k["k_nalias"] = np.int32(best[1])
-    k["k_factor3p"], k["k_factor3p_rows"] = pack(tr, plain_ops, plain, ring)
+    k["k_factor3p"], k["k_factor3p_rows"] = pack(tr, plain_ops, _split_wide(plain, W), ring, bk, True)
     inv = inverse_ops(tr)
-    k["k_linv"], k["k_linv_rows"] = pack(tr, inv, schedule(inv, weights=(1.0, 2.0)), ring)
+    k["k_linv"], k["k_linv_rows"] = pack(tr, inv, _split_wide(schedule(inv, W, weights=(1.0, 2.0)), W), ring, bk, False)
     return k
