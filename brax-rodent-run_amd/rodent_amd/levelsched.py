@@ -10,7 +10,7 @@ row sees everything earlier rows wrote and no row needs a wait of its own: WHICH
 
 Rounds 1-2 packed the operations level by level (all dofs of one tree depth, a hand-off after each level): 97 + 63 rows for the rodent,
 57 % of the slots filled, because the 35 levels of the trunk are nearly empty at the shallow end while the limbs' levels collide on the
-root's rows.  Here the operations are list-scheduled as ONE dependency graph per schedule: 59 + 44 rows.
+root's rows.  Here the operations are list-scheduled as ONE dependency graph per schedule: 57 + 44 rows.
 
 The hottest targets -- the 8 quads of the free joint's rows receive one contribution from EVERY other dof -- would serialise the schedule
 (one write per cell and row), so the side branches of a fork accumulate into private ALIAS copies of their ancestors' rows (cells that are
