@@ -9,8 +9,8 @@
 // Mapping: lanes run over bodies / dofs / contacts (element e -> lane e%64, slot e/64,
 // slot counts are template parameters so per-lane arrays stay in registers).  Kinematic-tree
 // recursions are pointer-doubling / DFS-range sweeps; the sparse L'DL factorisation and its explicit
-// inverse run as level schedules, the solves and M*x as balanced per-lane jobs (tables built in
-// rodent_amd/ktables.py); J*x and J'f are Jacobian-free.  No LDS atomics: every update has one owner
+// inverse run as list-scheduled row programs (rodent_amd/levelsched.py), the solves and M*x as balanced per-lane jobs
+// (rodent_amd/ktables.py); J*x and J'f are Jacobian-free.  No LDS atomics: every update has one owner
 // lane.  Reductions over dofs / rows are DPP wave sums in a fixed order.  Inactive constraint rows
 // contribute exactly zero in the reference formulation, so they are skipped.
 #pragma once
@@ -81,7 +81,7 @@ constexpr RRLayout rr_layout(int nq, int nv, int nu, int nbody, int nM, int ncon
   k.o_cdof = o; o += rr_up4(6 * nv + 6);     // + a zero motion vector for dof id nv (padding of the J*x jobs)
   k.o_cvel = o; o += rr_up4(6 * nbody);
   // sparse-matrix array of PAIRS (M | M + dt*diag(damping), then their factors, then their inverse factors): nM entries,
-  // the cells ZERO, ONE, TRASH (+ pad) of the level schedules, 16 zero cells padded row jobs read on.  Before the mass
+  // the cells ZERO, ONE, TRASH, MINUS_ONE of the row programs, 16 zero cells padded row jobs read on.  Before the mass
   // matrix is built its first cells hold cacc | cfrc and the sin/cos scratch.
   k.o_qLD = o; o += rr_up4(rr_imax(rr_imax(2 * (nM + 20), 12 * nbody), 2 * nv));
   k.o_vec = o; o += rr_up4(nv + 16);         // vector cells nv.. hold 0 (padding of the job descriptors; padded column steps read on)
@@ -1095,9 +1095,9 @@ struct Wave {
 
   // W = I - L^-1 (strictly lower part) in place of L: L^-1 has the tree sparsity of L (non-zero only for j an ancestor of
   // i).  The triangular solves of mj_solveLD are chains of ~2*depth dependent LDS hand-offs each and the step makes 11
-  // of them per factorisation; with W they become two independent sparse products (ldl_solve).  Gauss-Jordan by depth
-  // levels, shallow -> deep (k_linv): when the dofs k of a level are processed every descendant row i does
-  // W_ia -= W_ik W_ka over the strict ancestors a of k; W_ik still holds L_ik (only deeper levels write it), row k is final.
+  // of them per factorisation; with W they become two independent sparse products (ldl_solve).  Gauss-Jordan, shallow dofs
+  // first (k_linv, a row program like the factorisation's): for dof k every descendant row i does W_ia -= W_ik W_ka over the
+  // strict ancestors a of k; W_ik must still hold L_ik (deeper dofs overwrite it later) and row k must be final.
   __device__ __forceinline__ void invert() { run_levels<false>(PAIR ? T.linv + rep * D.inv_stride : T.linv, D.ninv); }
 
   // x <- (L' D L)^-1 x = U D^-1 U' x  [MuJoCo mj_solveLD] with the explicit inverse factor U = I - W (see invert): no

@@ -76,6 +76,17 @@ def test_model_load_dims_and_errors_without_gpu():
         hip.Model(bad)
 
 
+def test_blob_of_an_older_table_format_is_refused(tmp_path):
+    """round-1/2 blobs carry level schedules with flags and no alias-cell count: the row-program executor must not run them"""
+    tab = mjcf.load_blob(assets.asset_path("rodent_optimized"))
+    assert int(tab["k_nalias"]) > 0 and int(tab["k_factor3_rows"]) < int(tab["k_factor3p_rows"])
+    old = {k: v for k, v in tab.items() if k not in ("k_nalias", "k_factor3p", "k_factor3p_rows")}
+    path = str(tmp_path / "old.rrm")
+    mjcf.save_blob(old, path)
+    with pytest.raises(RuntimeError, match="lacks 'k_"):
+        hip.Model(path)
+
+
 @pytest.mark.parametrize("name,dims", [("rodent_optimized", (66, 74, 73, 30, 59, 303, 1119, 1263)),
                                        ("rodent_new", (67, 74, 73, 30, 57, 295, 1119, 1279)),
                                        ("rodent_pair", (133, 148, 146, 60, 114, 590, 2238, 2555)),
