@@ -87,6 +87,10 @@ static void layout(rr_model* m) {
   m->dims.lds_bytes = o * (int)sizeof(float);
   m->dims.dbg_floats = g;
   m->dims.solver = m->solver;
+  // 1: the production launches of this model run an instance compiled for its dimensions (rr_kernel.h RRDimsFixed); 0: the generic
+  // instance (same results, ~10 % slower).  The constants cover the schedule-table parameters, so a compiler change that moves
+  // them shows up here (tests/test_abi_and_oracle.py) instead of as a silent slowdown.
+  m->dims.fixed_instance = (m->solver != 2 && !m->dyn && m->NBS == 2 && m->NVS == 2 && m->NCS == 1 && (RRDimsRodent::matches(k) || RRDimsRodentNew::matches(k))) ? 1 : 0;
 }
 
 static kern_t pick_pair_kernel(const rr_model* m);

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("RR_LIB") or os.path.join(os.path.dirname(_HERE), "csr
 class RRDims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nM", "ncon", "nlimit",
                                          "nefc", "obs_dim", "iterations", "ls_iterations", "lds_bytes", "dbg_floats")] \
-        + [("timestep", C.c_float), ("solver", C.c_int32)]
+        + [("timestep", C.c_float), ("solver", C.c_int32), ("fixed_instance", C.c_int32)]
 
 
 class RRState(C.Structure):

@@ -39,6 +39,7 @@ typedef struct rr_dims {
   int32_t dbg_floats;                /* floats per env of the debug dump (rr_debug_layout) */
   float timestep;
   int32_t solver;                    /* 1 = CG, 2 = Newton (mjtSolver; opt.solver [REF Rodent_Env_Brax.py:42-45]) */
+  int32_t fixed_instance;            /* 1: stepped by a kernel instance compiled for these dimensions; 0: the generic instance (same results, slower) */
 } rr_dims;
 
 /* physics state of the batch: what survives between `pipeline_step` calls (mjx.Data qpos, qvel, act,

@@ -69,6 +69,9 @@ def test_model_load_dims_and_errors_without_gpu():
     assert (d.nq, d.nv, d.nu, d.nbody, d.ncon, d.nefc, d.obs_dim) == (74, 73, 30, 66, 59, 303, 1263)
     assert (d.iterations, d.ls_iterations) == (8, 8) and abs(d.timestep - 0.002) < 1e-9
     assert 0 < d.lds_bytes <= 160 * 1024 // 4            # four environments per CU
+    # the benchmark models run the instance compiled for their dimensions (incl. the schedule-table parameters ktables.py derives)
+    assert d.fixed_instance == 1 and hip.Model(assets.asset_path("rodent_new")).dims.fixed_instance == 1
+    assert hip.Model(assets.asset_path("rodent_pair")).dims.fixed_instance == 0
     with pytest.raises(RuntimeError, match="cannot open"):
         hip.Model("/nonexistent.rrm")
     bad = os.path.join(ROOT, "tests", "golden", "env_step_reset.json")
