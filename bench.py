@@ -157,6 +157,21 @@ def parse():
     return args
 
 
+class _stdout_to_stderr:
+    """Rank 0's stdout carries ONE JSON line: native libraries that greet on stdout while the process group forms (gloo prints its
+    peer count) are sent to stderr for that stretch (file-descriptor level, so C++ streams are covered)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start N copies of this command, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_* in their environment, as torch.distributed.run sets them), from a parent that never touches a GPU (no exec of a process
@@ -202,7 +217,8 @@ def cpu_rehearsal(args, rank, world):
     from rodent_amd.training.agents.ppo import train as ppo
     from tests.fake_env import PointEnv
     if world > 1:
-        dist.init_process_group("gloo")
+        with _stdout_to_stderr():
+            dist.init_process_group("gloo")
     times = []
     ppo.train(environment=PointEnv(16 * world), num_timesteps=10 ** 9, episode_length=20, num_envs=16 * world, batch_size=16 * world,
               num_minibatches=2, unroll_length=5, num_updates_per_batch=2, num_evals=2, num_eval_envs=0, normalize_observations=True, seed=0,
@@ -241,10 +257,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(dev_index)
-        if share:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        with _stdout_to_stderr():
+            if share:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
     else:
         dist = None
     dev = torch.device("cuda", dev_index)

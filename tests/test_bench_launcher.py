@@ -16,8 +16,8 @@ def _run(cmd, **env):
         e.pop(k, None)
     r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout       # ONE line on stdout: nothing else may greet there (gloo does, unless redirected)
     return json.loads(lines[0])
 
 
