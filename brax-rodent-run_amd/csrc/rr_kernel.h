@@ -23,7 +23,10 @@
 #ifndef RR_WIDE
 #define RR_WIDE 1
 #endif
-#define RR_RING 8    // rows of a level schedule in flight (ktables RING); 12 / 16 measured 2-3 % slower in round 2
+#ifndef RR_RING
+#define RR_RING 6    // table rows of a row program in flight (<= ktables RING = 8, the empty rows behind a program); round 2: 8 (12 / 16: 2-3 % slower);
+                     // with the shorter round-3 programs 6 is best under the driver protocol (2: +0.2 %, 3-5: +1.0 %, 6: +1.5 % against 8)
+#endif
 
 #define RR_NPH 24    // phases of the diagnostic (s_memtime) build
 #ifndef RR_ENV_PRIO
@@ -957,7 +960,7 @@ struct Wave {
   // empty operations / the unused targets of short runs address the cells ZERO (0.0), ONE (1.0) and TRASH kept behind the
   // nM entries (MINUS_ONE (-1.0) is the shared operand of a merge).
   // 1/piv: v_rcp_f32 refined by one Newton step (the row scaling by 1/D after the sweep uses the exact quotient).
-  // Rows (16 B per lane) are prefetched RR_RING ahead; the table ends with RR_RING empty rows.
+  // Rows (16 B per lane) are prefetched RR_RING ahead; the table ends with 8 >= RR_RING empty rows.
   typedef float __attribute__((address_space(3)))* rr_lf;
   static __device__ __forceinline__ float lds_ld(int byte_adr) { return *(rr_lf)(size_t)(unsigned)byte_adr; }
   static __device__ __forceinline__ void lds_st(int byte_adr, float v) { *(rr_lf)(size_t)(unsigned)byte_adr = v; }
