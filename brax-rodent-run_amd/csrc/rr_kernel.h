@@ -29,6 +29,11 @@
 #endif
 
 #define RR_NPH 24    // phases of the diagnostic (s_memtime) build
+#ifndef RR_W1                // contacts in penetration from which an environment's waves run at priority 1 / 2 / 3
+#define RR_W1 2
+#define RR_W2 6
+#define RR_W3 12
+#endif
 #ifndef RR_ENV_PRIO
 #define RR_ENV_PRIO 1      // graded wave priority by contacts in penetration (see the kernel body)
 #endif
@@ -510,7 +515,7 @@ struct Wave {
     return;
 #endif
     // ... raised for an environment that has fallen behind the others of a multi-step launch (lag_prio, set by the kernel per env step)
-    const int by_weight = jnact >= 12 ? 3 : (jnact >= 6 ? 2 : (jnact >= 2 ? 1 : 0));
+    const int by_weight = jnact >= RR_W3 ? 3 : (jnact >= RR_W2 ? 2 : (jnact >= RR_W1 ? 1 : 0));
     int p = by_weight > lag_prio ? by_weight : lag_prio;
     if ((lag_mode & 3) == 1) p = lag_prio;                                         // progress only
     else if ((lag_mode & 3) == 2) p = by_weight + lag_prio > 3 ? 3 : by_weight + lag_prio;
