@@ -783,13 +783,43 @@ extern "C" int rr_mlp_forward(const float* obs, const int64_t* obs_rows, int32_t
   A.obs = obs; A.rows = obs_rows; A.M = M; A.K = K; A.mean = mean; A.std_ = std_;
   A.pol_out = policy_out; A.val_out = value_out; A.pol_act = policy ? policy_pre : nullptr; A.val_act = value ? value_pre : nullptr;
   const size_t lds = RR_MLP_LDS_FLOATS * sizeof(float);
+  typedef void (*fwd_t)(const RRMlpArgs);
+  const fwd_t kern = policy && value ? (fwd_t)rr_mlp_forward_kernel<true, true> : (value ? (fwd_t)rr_mlp_forward_kernel<true, false> : (fwd_t)rr_mlp_forward_kernel<false, true>);
   static bool attr_set = false;
   if (!attr_set) {
-    HIPCHK(hipFuncSetAttribute((const void*)rr_mlp_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (fwd_t k_ : {(fwd_t)rr_mlp_forward_kernel<true, true>, (fwd_t)rr_mlp_forward_kernel<true, false>, (fwd_t)rr_mlp_forward_kernel<false, true>})
+      HIPCHK(hipFuncSetAttribute((const void*)k_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(rr_mlp_forward_kernel, dim3((M + RR_MLP_BM - 1) / RR_MLP_BM), dim3(256), lds, (hipStream_t)stream, A);
+  // diagnostic (RR_MLP_PROF=<file>, eager calls only): shader-clock stamps per phase and workgroup, summarised into the file after every call
+  static const char* prof_path = getenv("RR_MLP_PROF");
+  static unsigned long long* prof_dev = nullptr;
+  const int nwg = (M + RR_MLP_BM - 1) / RR_MLP_BM;
+  if (prof_path && nwg <= 4096) {
+    if (!prof_dev) HIPCHK(hipMalloc((void**)&prof_dev, 4096 * 16 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(prof_dev, 0, (size_t)nwg * 16 * sizeof(unsigned long long), (hipStream_t)stream));
+    A.prof = prof_dev;
+  }
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, (hipStream_t)stream, A);
   HIPCHK(hipGetLastError());
+  if (A.prof) {
+    std::vector<unsigned long long> h((size_t)nwg * 16);
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    HIPCHK(hipMemcpy(h.data(), prof_dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(prof_path, "a")) {
+      unsigned long long t0 = ~0ull, t1 = 0;
+      double sum[16] = {0};
+      for (int w = 0; w < nwg; ++w) {
+        t0 = std::min(t0, h[(size_t)w * 16]); t1 = std::max(t1, h[(size_t)w * 16 + 12]);
+        unsigned long long prev = h[(size_t)w * 16];
+        for (int i = 1; i <= 12; ++i) { const unsigned long long v = h[(size_t)w * 16 + i]; if (v) { sum[i] += (double)(v - prev); prev = v; } }
+      }
+      fprintf(f, "M %d workgroups %d span %llu ticks; mean ticks per workgroup: layer1_loop %.0f layer1_store %.0f policy %.0f", M, nwg, t1 - t0, sum[1] / nwg, sum[2] / nwg, sum[3] / nwg);
+      for (int l = 1; l <= 4; ++l) fprintf(f, " | hidden%d loop %.0f store %.0f", l, sum[2 + 2 * l] / nwg, sum[3 + 2 * l] / nwg);
+      fprintf(f, " | head %.0f\n", sum[12] / nwg);
+      fclose(f);
+    }
+  }
   return RR_OK;
 }
 

@@ -42,6 +42,7 @@ struct RRMlpArgs {
   float* val_out;                            // [M]
   float* pol_act;                            // nullable: [pol.nlayers-1][M][32]   hidden PRE-activations z = h W' + b (for a backward pass)
   float* val_act;                            // nullable: [val.nlayers-1][M][256]
+  unsigned long long* prof;                  // nullable, diagnostic (RR_MLP_PROF): [workgroups][16] shader-clock stamps per phase
 };
 
 typedef float rr_f4 __attribute__((ext_vector_type(4)));
@@ -197,9 +198,17 @@ __device__ __forceinline__ void rr_mlp_store_pol(float* actP, const rr_f4& ap, c
 #ifndef RR_MLP_RCP
 #define RR_MLP_RCP 0         // 1: multiply by a refined reciprocal instead of dividing -- measured 0.443 vs 0.446-0.450 ms, within noise, so the IEEE division (what the reference computes) stays
 #endif
+#ifndef RR_MLP_NO_NORM
+#define RR_MLP_NO_NORM 0      // 1 (experiment): the normaliser compiled out of the forward (pre-normalised observations)
+#endif
 #ifndef RR_MLP_STAGES
 #define RR_MLP_STAGES 1      // register stages of layer 1's chunks (2: chunk c+2 in flight during chunk c; needs more than 168 VGPRs)
 #endif
+// HV / HP: which networks the launch carries, as template constants.  As run-time flags they left a three-way branch inside layer 1's chunk
+// loop; the compiler kept the 36 accumulator registers in different places on its arms and joined them with 32 v_mov per chunk behind an
+// s_nop 15 (the MFMA-result hazard), i.e. every chunk waited for its matrix work to drain: layer 1 ran 6300 ticks per chunk against 2200
+// for the identically shaped chunks of the hidden layers (RR_MLP_PROF stamps, tools/pmc_forward_rows.py).
+template <bool HV, bool HP>
 __global__ __launch_bounds__(256, RR_MLP_FWD_WGS) void rr_mlp_forward_kernel(const RRMlpArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* actV = lds;                                 // region A: [32][258] value activations ...
@@ -209,8 +218,10 @@ __global__ __launch_bounds__(256, RR_MLP_FWD_WGS) void rr_mlp_forward_kernel(con
   float* actP = sB + RR_MLP_ACTP_AT;                 //   ... [32][34] policy activations
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int row0 = blockIdx.x * RR_MLP_BM;
-  const bool has_val = A.val.nlayers > 0, has_pol = A.pol.nlayers > 0;
+  constexpr bool has_val = HV, has_pol = HP;
   const int M = A.M, K = A.K;
+  auto stamp = [&](int i) { if (A.prof && threadIdx.x == 0) A.prof[(size_t)blockIdx.x * 16 + i] = __builtin_amdgcn_s_memtime(); };
+  stamp(0);
 
   // ------------------------------------------------------------------ layer 1 of both nets: one pass over the observation
   {
@@ -235,7 +246,7 @@ __global__ __launch_bounds__(256, RR_MLP_FWD_WGS) void rr_mlp_forward_kernel(con
       constexpr bool FULL = decltype(full)::value;
       const int k0 = c * RR_MLP_KC;
       S.gx.template fetch_at<FULL>(A.obs, xoff, k0, K);
-      if (A.mean) {      // the normaliser's chunk rides along; it is APPLIED at commit time (arithmetic on the loaded values here
+      if (!RR_MLP_NO_NORM && A.mean) {      // the normaliser's chunk rides along; it is APPLIED at commit time (arithmetic on the loaded values here
 #pragma unroll       // would wait for them -- and for every older load -- inside the fetch, i.e. no load would ever fly during the MFMAs)
         for (int i = 0; i < RRStage<RR_MLP_BM>::PER; ++i) {
           const int k = k0 + 4 * ((threadIdx.x + 256 * i) & 3);
@@ -255,7 +266,7 @@ __global__ __launch_bounds__(256, RR_MLP_FWD_WGS) void rr_mlp_forward_kernel(con
       else fetch_t(S, c, std::false_type{});
     };
     auto step = [&](Stage& S, int c) {
-      if (A.mean) {      // normalise in registers: (x - mean) / std  (running_statistics.normalize); columns past K meet zero weights
+      if (!RR_MLP_NO_NORM && A.mean) {      // normalise in registers: (x - mean) / std  (running_statistics.normalize); columns past K meet zero weights
 #pragma unroll
         for (int i = 0; i < RRStage<RR_MLP_BM>::PER; ++i)
 #pragma unroll
@@ -275,9 +286,7 @@ __global__ __launch_bounds__(256, RR_MLP_FWD_WGS) void rr_mlp_forward_kernel(con
       if (has_pol) S.gp.commit(sW + RR_MLP_VH * RR_SX);
       __syncthreads();
       if (c + RR_MLP_STAGES < nchunk) fetch(S, c + RR_MLP_STAGES);
-      if (has_val && has_pol) rr_mlp_chunk<true, true>(sX, RR_SX, 0, sW, RR_MLP_VH, a0, a1, ap, lane, wv);
-      else if (has_val) rr_mlp_chunk<true, false>(sX, RR_SX, 0, sW, RR_MLP_VH, a0, a1, ap, lane, wv);
-      else rr_mlp_chunk<false, true>(sX, RR_SX, 0, sW, RR_MLP_VH, a0, a1, ap, lane, wv);
+      rr_mlp_chunk<HV, HP>(sX, RR_SX, 0, sW, RR_MLP_VH, a0, a1, ap, lane, wv);
       __syncthreads();
     };
 #if RR_MLP_STAGES == 2
@@ -291,9 +300,11 @@ __global__ __launch_bounds__(256, RR_MLP_FWD_WGS) void rr_mlp_forward_kernel(con
     fetch(S0, 0);
     for (int c = 0; c < nchunk; ++c) step(S0, c);
 #endif
+    stamp(1);
     if (has_val) rr_mlp_store_val(actV, a0, a1, A.val.b[0], lane, wv, A.val_act, row0, M);
     if (has_pol) rr_mlp_store_pol(actP, ap, A.pol.b[0], lane, wv, A.pol_act, row0, M);
     __syncthreads();
+    stamp(2);
   }
 
   // ------------------------------------------------------------------ policy hidden layers 32 -> 32 and the head 32 -> out_dim (region B)
@@ -339,14 +350,17 @@ __global__ __launch_bounds__(256, RR_MLP_FWD_WGS) void rr_mlp_forward_kernel(con
     }
   }
   __syncthreads();        // the policy is done with region B
+  stamp(3);
   // ------------------------------------------------------------------ value hidden layers 256 -> 256 (activations stay in LDS; weight chunks through region B)
   for (int l = 1; has_val && l < A.val.nlayers - 1; ++l) {
     rr_f16 a0 = {0}, a1 = {0};
     rr_f4 ap = {0, 0, 0, 0};
     rr_mlp_hidden_layer(A.val.W[l], actV, sB, a0, a1, ap, lane, wv);
+    stamp(2 + 2 * l);
     // every wave has read the whole input before anyone overwrites it (the barrier closing the last chunk)
     rr_mlp_store_val(actV, a0, a1, A.val.b[l], lane, wv, A.val_act ? A.val_act + (size_t)l * M * RR_MLP_VH : nullptr, row0, M);
     __syncthreads();
+    stamp(3 + 2 * l);
   }
   // value head 256 -> 1: eight lanes per row
   if (has_val) {
@@ -359,6 +373,7 @@ __global__ __launch_bounds__(256, RR_MLP_FWD_WGS) void rr_mlp_forward_kernel(con
     s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
     if (part == 0 && row0 + m < M) A.val_out[row0 + m] = s + A.val.b[l][0];
   }
+  stamp(12);
 }
 
 // ------------------------------------------------------------------------------------------ value network, backward: the delta chain

@@ -6,7 +6,7 @@ import torch
 from rodent_amd import hip
 from rodent_amd.training import fused_mlp, networks
 dev = "cuda:0"
-K, M = 1263, 22528
+K, M = int(os.environ.get("RR_K", 1263)), 22528
 torch.manual_seed(0)
 n = networks.make_ppo_networks(K, 30, device=dev)
 pp, vp = fused_mlp.net_params(n.policy_network), fused_mlp.net_params(n.value_network)
