@@ -49,6 +49,21 @@ typedef float rr_f4 __attribute__((ext_vector_type(4)));
 typedef float rr_f16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float rr_silu(float v) { return v / (1.0f + expf(-v)); }
+// sigmoid for the VALUE network's 256-wide epilogues (forward and backward: 32 values per thread and layer, where libm's expf + the IEEE
+// quotient were ~25 instructions per value = the bulk of the "store" phases): v_exp_f32 on x log2(e) and a reciprocal refined by one Newton
+// step, each <= 1 ulp.  The policy network keeps rr_silu: its forward must agree bit for bit with the rollout's actor (rr_kernel.h, rr_ppo.h).
+#ifndef RR_MLP_FAST_SIGMOID
+#define RR_MLP_FAST_SIGMOID 1
+#endif
+__device__ __forceinline__ float rr_sigmoid_val(float v) {
+#if RR_MLP_FAST_SIGMOID
+  const float e = __builtin_amdgcn_exp2f(fminf(-1.4426950408889634f * v, 126.0f));      // exp(-v); clamped: 1 + 2^126 stays finite
+  const float d = 1.0f + e, r = __builtin_amdgcn_rcpf(d);
+  return r * (2.0f - d * r);
+#else
+  return 1.0f / (1.0f + expf(-v));
+#endif
+}
 
 constexpr int RR_SX = RR_MLP_KC + 2;        // stage stride (18): 18 n mod 64 is a bijection of n = 0..31 onto the even banks
 constexpr int RR_SV = RR_MLP_VH + 2;        // value activation stride (258)
@@ -173,7 +188,7 @@ __device__ __forceinline__ void rr_mlp_store_val(float* actV, const rr_f16& a0, 
     for (int r = 0; r < 16; ++r) {
       const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       const float z = (t ? a1[r] : a0[r]) + bn;
-      actV[m * RR_SV + n] = rr_silu(z);
+      actV[m * RR_SV + n] = z * rr_sigmoid_val(z);
       if (dump && row0 + m < M) dump[(size_t)(row0 + m) * RR_MLP_VH + n] = z;
     }
   }
@@ -414,7 +429,7 @@ __device__ __forceinline__ void rr_mlp_bwd_epilogue(const RRMlpBwdArgs& A, int j
       float d = 0.0f;
       if (row0 + m < A.M) {
         const size_t i = (size_t)(row0 + m) * RR_MLP_VH + n;
-        const float zz = zj[i], s = 1.0f / (1.0f + expf(-zz));
+        const float zz = zj[i], s = rr_sigmoid_val(zz);
         d = (HEAD ? gm[r] * wn : (t ? a1[r] : a0[r])) * (s * (1.0f + zz * (1.0f - s)));
         dj[i] = d;
         zj[i] = zz * s;
